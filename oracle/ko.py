@@ -1,0 +1,182 @@
+"""ctypes binding of the TEST-ONLY CPU oracle (oracle/keisei_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (shogidrl_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_DIR, "libkeisei_oracle.so")
+
+NUM_ACTIONS = 13527
+OBS_SIZE = 46 * 81
+
+
+def build(force=False):
+    src = os.path.join(_DIR, "keisei_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _DIR, "-s"] + (["-B"] if force else []))
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.ko_new.restype = C.c_void_p
+        L.ko_new.argtypes = [C.c_int]
+        L.ko_free.argtypes = [C.c_void_p]
+        L.ko_reset.argtypes = [C.c_void_p]
+        L.ko_from_sfen.argtypes = [C.c_void_p, C.c_char_p]
+        L.ko_legal_ids.argtypes = [C.c_void_p, C.c_void_p]
+        L.ko_is_in_check.argtypes = [C.c_void_p, C.c_int]
+        L.ko_make_move.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        L.ko_observation.argtypes = [C.c_void_p, C.c_void_p]
+        L.ko_legal_mask.argtypes = [C.c_void_p, C.c_void_p]
+        L.ko_export_state.argtypes = [C.c_void_p, C.c_void_p]
+        L.ko_encode_action.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.ko_decode_action.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.ko_vec_step.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 9 + [C.c_int]
+        L.ko_gae.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                             C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class _KoGameStruct(C.Structure):
+    _fields_ = [("board", C.c_int8 * 81), ("hands", (C.c_uint8 * 8) * 2), ("side", C.c_int32),
+                ("move_count", C.c_int32), ("max_moves", C.c_int32), ("game_over", C.c_int32),
+                ("winner", C.c_int32), ("reason", C.c_int32), ("hist_len", C.c_int32),
+                ("hist_cap", C.c_int32), ("hist", C.c_void_p)]
+
+
+class Game:
+    """One oracle game (mirrors the slice of keisei.shogi.ShogiGame the hot path uses)."""
+
+    def __init__(self, max_moves=500, sfen=None):
+        self._L = lib()
+        self._h = self._L.ko_new(int(max_moves))
+        if sfen is not None:
+            if self._L.ko_from_sfen(self._h, sfen.encode()) != 0:
+                self._L.ko_free(self._h)
+                self._h = None
+                raise ValueError("invalid SFEN: %r" % sfen)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.ko_free(self._h)
+            self._h = None
+
+    @property
+    def s(self):
+        return C.cast(self._h, C.POINTER(_KoGameStruct)).contents
+
+    side = property(lambda self: int(self.s.side))
+    move_count = property(lambda self: int(self.s.move_count))
+    game_over = property(lambda self: bool(self.s.game_over))
+    winner = property(lambda self: int(self.s.winner))
+    reason = property(lambda self: int(self.s.reason))
+
+    def reset(self):
+        self._L.ko_reset(self._h)
+
+    def legal_ids(self):
+        buf = np.zeros(1024, np.uint16)
+        n = self._L.ko_legal_ids(self._h, buf.ctypes.data)
+        return buf[:n].copy()
+
+    def in_check(self, color):
+        return bool(self._L.ko_is_in_check(self._h, int(color)))
+
+    def make_move(self, action):
+        r = C.c_float(0)
+        d = C.c_int(0)
+        rc = self._L.ko_make_move(self._h, int(action), C.byref(r), C.byref(d))
+        if rc != 0:
+            raise ValueError("illegal move pattern for action %d" % action)
+        return float(r.value), bool(d.value)
+
+    def observation(self):
+        o = np.zeros(OBS_SIZE, np.float32)
+        self._L.ko_observation(self._h, o.ctypes.data)
+        return o.reshape(46, 9, 9)
+
+    def legal_mask(self):
+        m = np.zeros(NUM_ACTIONS, np.uint8)
+        self._L.ko_legal_mask(self._h, m.ctypes.data)
+        return m
+
+    def export_state(self):
+        b = np.zeros(128, np.uint8)
+        self._L.ko_export_state(self._h, b.ctypes.data)
+        return b
+
+
+class VecGames:
+    """N independent oracle games stepped together (CPU baseline / batched parity checker)."""
+
+    def __init__(self, n, max_moves=500):
+        self._L = lib()
+        self.n = n
+        self.games = [Game(max_moves) for _ in range(n)]
+        self._ptrs = (C.c_void_p * n)(*[g._h for g in self.games])
+
+    def observe(self):
+        obs = np.zeros((self.n, 46, 9, 9), np.float32)
+        mask = np.zeros((self.n, NUM_ACTIONS), np.uint8)
+        nl = np.zeros(self.n, np.int32)
+        for i, g in enumerate(self.games):
+            obs[i] = g.observation()
+            mask[i] = g.legal_mask()
+            nl[i] = int(mask[i].sum())
+        return obs, mask, nl
+
+    def step(self, actions, auto_reset=True, lo=0, hi=None):
+        hi = self.n if hi is None else hi
+        n = hi - lo
+        actions = np.ascontiguousarray(actions, np.int64)
+        obs = np.zeros((n, 46, 9, 9), np.float32)
+        mask = np.zeros((n, NUM_ACTIONS), np.uint8)
+        nl = np.zeros(n, np.int32)
+        rew = np.zeros(n, np.float32)
+        done = np.zeros(n, np.uint8)
+        reason = np.zeros(n, np.uint8)
+        winner = np.zeros(n, np.int8)
+        ptrs = C.cast(C.byref(self._ptrs, lo * C.sizeof(C.c_void_p)), C.c_void_p)
+        self._L.ko_vec_step(ptrs, n, actions.ctypes.data, obs.ctypes.data, mask.ctypes.data,
+                            nl.ctypes.data, rew.ctypes.data, done.ctypes.data, reason.ctypes.data,
+                            winner.ctypes.data, int(auto_reset))
+        return obs, mask, nl, rew, done, reason, winner
+
+
+def gae(rewards, values, dones, last_values, gamma, lam):
+    """rewards/values/dones: [T,N]; last_values: [N]. Returns (adv, ret) float32 [T,N]."""
+    r = np.ascontiguousarray(rewards, np.float32)
+    v = np.ascontiguousarray(values, np.float32)
+    d = np.ascontiguousarray(dones, np.uint8)
+    lv = np.ascontiguousarray(last_values, np.float32)
+    T, N = r.shape
+    adv = np.zeros((T, N), np.float32)
+    ret = np.zeros((T, N), np.float32)
+    lib().ko_gae(r.ctypes.data, v.ctypes.data, d.ctypes.data, lv.ctypes.data, float(gamma), float(lam),
+                 T, N, adv.ctypes.data, ret.ctypes.data)
+    return adv, ret
+
+
+def encode_action(from_sq, to_sq, aux):
+    return lib().ko_encode_action(int(from_sq), int(to_sq), int(aux))
+
+
+def decode_action(a):
+    f, t, x = C.c_int(), C.c_int(), C.c_int()
+    if lib().ko_decode_action(int(a), C.byref(f), C.byref(t), C.byref(x)) != 0:
+        raise IndexError(a)
+    return f.value, t.value, x.value
