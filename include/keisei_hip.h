@@ -1,0 +1,149 @@
+/*
+ * keisei_hip.h -- C-ABI of libkeisei_hip.so, the MI355X (gfx950) implementation of the Keisei
+ * (tachyon-beep/shogidrl) self-play + PPO hot path.
+ *
+ * The reference has no FFI: the path is ordinary Python method calls.  Each entry
+ * point below therefore cites the reference *Python* interface it replaces (paths relative to
+ * /root/reference/keisei/), and INTEGRATION.md shows the ctypes binding a Keisei maintainer would add.
+ *
+ * Conventions
+ *   - every pointer marked "dev" is caller-owned DEVICE memory (e.g. torch.Tensor.data_ptr()) on the
+ *     device the handle was created on; "host" pointers are ordinary host memory;
+ *   - every launch goes to the caller-supplied stream (hipStream_t passed as void*; NULL = default
+ *     stream); no entry point synchronises unless it says so, none allocates after *_create, so
+ *     all *_step / *_reset / kernels are hipGraph-capturable;
+ *   - return value: 0 = OK, negative = KSH_E_* ; never throws; handles are not thread-safe;
+ *   - tensors are dense row-major with exactly the reference's shapes and dtypes:
+ *       obs   float32 [N,46,9,9]   (shogi/shogi_game_io.py:434-539)
+ *       mask  uint8   [N,13527]    (utils/utils.py:310-336; torch.bool has the same 1-byte layout)
+ *       action int64  [N]          (utils/utils.py:183-266 index space)
+ */
+#ifndef KEISEI_HIP_H
+#define KEISEI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KSH_NUM_ACTIONS 13527 /* constants.py:15 */
+#define KSH_OBS_PLANES 46
+#define KSH_OBS_FLOATS (46 * 81)
+#define KSH_STATE_BYTES 128
+
+/* error codes */
+#define KSH_OK 0
+#define KSH_E_ARG (-1)     /* bad argument (null pointer, size, misaligned buffer) */
+#define KSH_E_HIP (-2)     /* a HIP runtime call failed; see ksh_last_error() */
+#define KSH_E_STATE (-3)   /* invalid game state handed to ksh_env_set_state */
+
+/* termination reason codes written to reason[] (shogi/shogi_core_definitions.py:135-141) */
+#define KSH_REASON_ONGOING 0    /* "Game ongoing" (shogi_game.py:567-569) */
+#define KSH_REASON_TSUMI 1      /* "Tsumi" */
+#define KSH_REASON_STALEMATE 2  /* "stalemate" */
+#define KSH_REASON_MAX_MOVES 3  /* "Max moves reached" */
+#define KSH_REASON_SENNICHITE 4 /* "Sennichite" */
+#define KSH_REASON_ILLEGAL 5    /* action rejected (the reference's ValueError -> episode reset,
+                                   training/step_manager.py:303-348) */
+
+const char *ksh_last_error(void);
+int ksh_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batched environment.  Replaces, for N games at once:
+ *   ShogiGame(max_moves_per_game)                     shogi/shogi_game.py:39-54
+ *   ShogiGame.reset()                                  shogi/shogi_game.py:113-130
+ *   ShogiGame.get_legal_moves()                        shogi/shogi_game.py:216 -> shogi_rules_logic.py:486-635
+ *   PolicyOutputMapper.get_legal_mask(moves, device)   utils/utils.py:310-336
+ *   ShogiGame.make_move(move)                          shogi/shogi_game.py:574-660 (+ termination :408-450,
+ *                                                      sennichite shogi_rules_logic.py:638-695)
+ *   ShogiGame.get_observation()                        shogi/shogi_game_io.py:434-539
+ *   StepManager episode reset on done                  training/step_manager.py:437-468
+ * ---------------------------------------------------------------------------------------------- */
+int ksh_env_create(int device, int n_games, int max_moves, void **handle);
+int ksh_env_destroy(void *handle);
+int ksh_env_num_games(void *handle);
+int ksh_env_max_moves(void *handle);
+
+/* Reset the games whose reset_mask[g] != 0 (all games when reset_mask == NULL) to the initial position
+ * and write obs / legal mask / legal-move count of EVERY game (non-reset games are re-observed). */
+int ksh_env_reset(void *handle, const uint8_t *reset_mask /*dev [N] or NULL*/, float *obs /*dev*/,
+                  uint8_t *legal_mask /*dev*/, int32_t *n_legal /*dev [N]*/, void *stream);
+
+/* Re-encode the current state of every game without changing it (observation + legal mask). */
+int ksh_env_observe(void *handle, float *obs /*dev*/, uint8_t *legal_mask /*dev*/, int32_t *n_legal /*dev*/, void *stream);
+
+/* One env step for every game: apply actions[g], detect termination, optionally auto-reset finished
+ * games, then write the NEXT observation / legal mask (of the reset position for finished games when
+ * auto_reset != 0, exactly as StepManager discards the terminal observation).
+ *   reward[g]  +1.0 iff the mover delivered Tsumi, else 0.0      (shogi_game.py:553-566)
+ *   done[g]    1 iff the game ended with this move
+ *   reason[g]  KSH_REASON_*, winner[g]  -1 none / 0 black / 1 white
+ * prev_mask (nullable): the legal mask of the position the action is taken from (normally the buffer
+ * the previous call wrote; it may alias next_mask).  When given, an action whose mask byte is 0 is
+ * rejected with KSH_REASON_ILLEGAL instead of being applied. */
+int ksh_env_step(void *handle, const int64_t *actions /*dev [N]*/, const uint8_t *prev_mask /*dev or NULL*/,
+                 float *next_obs /*dev*/, uint8_t *next_mask /*dev*/, int32_t *n_legal /*dev*/,
+                 float *reward /*dev*/, uint8_t *done /*dev*/, uint8_t *reason /*dev*/, int8_t *winner /*dev*/,
+                 int auto_reset, void *stream);
+
+/* Host-side state exchange for tests / fixtures (ShogiGame.from_sfen, shogi_game.py:283-345, is host
+ * code: parse the SFEN on the host, then hand the packed 128-byte record over).  Both calls
+ * synchronise the given stream.  Record layout: bytes 0-80 board (0 empty, else 1+type+14*color,
+ * sq=row*9+col), 81-87 black hand P..R, 88-94 white hand, 95 side to move, 96-97 move_count (LE),
+ * 98 game_over, 99 reason, 100 winner+1, 102-103 history base (LE), rest zero. */
+int ksh_env_set_state(void *handle, int game, const uint8_t *state128 /*host*/, void *stream);
+int ksh_env_get_state(void *handle, int game, uint8_t *state128 /*host*/, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Masked categorical action selection.  Replaces BaseActorCriticModel.get_action_and_value's tail
+ * (core/base_actor_critic.py:64-116): masked softmax -> Categorical(probs) sample (or argmax when
+ * deterministic) -> log_prob, for B rows at once.  logits_dtype: 0 = float32, 1 = bfloat16.
+ * RNG: counter-based Philox4x32-10 keyed by (seed, step), one stream per row.
+ * ---------------------------------------------------------------------------------------------- */
+int ksh_masked_sample(const void *logits /*dev [B,A]*/, int logits_dtype, const uint8_t *mask /*dev [B,A]*/,
+                      int B, uint64_t seed, uint64_t step, int deterministic,
+                      int64_t *action /*dev [B]*/, float *log_prob /*dev [B]*/, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GAE.  Replaces ExperienceBuffer.compute_advantages_and_returns (core/experience_buffer.py:99-145)
+ * for N independent streams stored [T,N] row-major (N = 1 is the reference's single stream).
+ * Bit-exact float32 op order; gamma/lambda are doubles because the reference folds them in Python
+ * doubles before the float32 multiply.
+ * ---------------------------------------------------------------------------------------------- */
+int ksh_gae_scan(const float *rewards /*dev [T,N]*/, const float *values /*dev [T,N]*/,
+                 const uint8_t *dones /*dev [T,N]*/, const float *last_values /*dev [N]*/,
+                 double gamma, double lambda, int T, int N,
+                 float *advantages /*dev [T,N]*/, float *returns /*dev [T,N]*/, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused PPO clipped-surrogate loss, forward + backward.  Replaces evaluate_actions' tail
+ * (core/base_actor_critic.py:147-184) and the loss lines of PPOAgent.learn (core/ppo_agent.py:340-383)
+ * for one minibatch of B samples:
+ *   loss = policy_loss + vf_coef * value_loss + ent_coef * (-mean entropy)
+ * Outputs d(loss)/d(logits) [B,A] (same dtype as logits), d(loss)/d(values) [B] and
+ * stats[8] = {loss, policy_loss, value_loss, entropy_loss(-mean H), kl_approx, clip_fraction, 0, 0}.
+ * value_clip != 0 selects the clipped value loss (ppo_agent.py:357-369).
+ * workspace: dev scratch of at least ksh_ppo_loss_workspace_bytes(B) bytes.
+ * ---------------------------------------------------------------------------------------------- */
+uint64_t ksh_ppo_loss_workspace_bytes(int B);
+int ksh_ppo_loss_fwd_bwd(const void *logits /*dev [B,A]*/, int logits_dtype, const uint8_t *mask /*dev [B,A]*/,
+                         const int64_t *actions /*dev [B]*/, const float *old_log_probs /*dev [B]*/,
+                         const float *advantages /*dev [B]*/, const float *returns /*dev [B]*/,
+                         const float *values /*dev [B]*/, const float *old_values /*dev [B]*/, int B,
+                         float clip_eps, float vf_coef, float ent_coef, int value_clip,
+                         void *dlogits /*dev [B,A]*/, float *dvalues /*dev [B]*/, float *stats /*dev [8]*/,
+                         void *workspace /*dev*/, void *stream);
+
+/* hipEvent helpers so that host code without a HIP binding (bench.py) can time launches on the very
+ * stream they were issued on.  ksh_event_elapsed_ms synchronises on `stop`. */
+int ksh_event_create(void **event);
+int ksh_event_record(void *event, void *stream);
+int ksh_event_elapsed_ms(void *start, void *stop, float *ms /*host*/);
+int ksh_event_destroy(void *event);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -44,7 +44,7 @@ def lib():
         L.ko_export_state.argtypes = [C.c_void_p, C.c_void_p]
         L.ko_encode_action.argtypes = [C.c_int, C.c_int, C.c_int]
         L.ko_decode_action.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
-        L.ko_vec_step.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 9 + [C.c_int]
+        L.ko_vec_step.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int]
         L.ko_gae.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
                              C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L

@@ -1,0 +1,62 @@
+"""ctypes binding of libkeisei_hip.so (include/keisei_hip.h).  There is NO fallback: if the HIP
+library is missing or fails to load, importing anything that computes raises."""
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libkeisei_hip.so")
+
+NUM_ACTIONS = 13527
+OBS_SHAPE = (46, 9, 9)
+
+_lib = None
+
+# every symbol include/keisei_hip.h declares (tests check the .so exports each of them)
+SYMBOLS = [
+    "ksh_last_error", "ksh_version", "ksh_env_create", "ksh_env_destroy", "ksh_env_num_games", "ksh_env_max_moves",
+    "ksh_env_reset", "ksh_env_observe", "ksh_env_step", "ksh_env_set_state", "ksh_env_get_state", "ksh_masked_sample",
+    "ksh_gae_scan", "ksh_ppo_loss_workspace_bytes", "ksh_ppo_loss_fwd_bwd", "ksh_event_create", "ksh_event_record",
+    "ksh_event_elapsed_ms", "ksh_event_destroy",
+]
+
+
+class KeiseiHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KeiseiHipError(
+            "shogidrl_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double
+    L.ksh_last_error.restype = C.c_char_p
+    L.ksh_env_create.argtypes = [i32, i32, i32, C.POINTER(vp)]
+    L.ksh_env_destroy.argtypes = [vp]
+    L.ksh_env_num_games.argtypes = [vp]
+    L.ksh_env_max_moves.argtypes = [vp]
+    L.ksh_env_reset.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.ksh_env_observe.argtypes = [vp, vp, vp, vp, vp]
+    L.ksh_env_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    L.ksh_env_set_state.argtypes = [vp, i32, vp, vp]
+    L.ksh_env_get_state.argtypes = [vp, i32, vp, vp]
+    L.ksh_masked_sample.argtypes = [vp, i32, vp, i32, u64, u64, i32, vp, vp, vp]
+    L.ksh_gae_scan.argtypes = [vp, vp, vp, vp, f64, f64, i32, i32, vp, vp, vp]
+    L.ksh_ppo_loss_workspace_bytes.restype = u64
+    L.ksh_ppo_loss_workspace_bytes.argtypes = [i32]
+    L.ksh_ppo_loss_fwd_bwd.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp]
+    L.ksh_event_create.argtypes = [C.POINTER(vp)]
+    L.ksh_event_record.argtypes = [vp, vp]
+    L.ksh_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(f32)]
+    L.ksh_event_destroy.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise KeiseiHipError("%s failed (%d): %s" % (what, rc, lib().ksh_last_error().decode()))

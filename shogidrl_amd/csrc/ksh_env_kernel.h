@@ -1,0 +1,688 @@
+// ksh_env_kernel.h -- the batched Shogi environment kernel for gfx950 (CDNA4), one game per wavefront.
+//
+// What it replaces (reference = /root/reference/keisei/):
+//   shogi/shogi_rules_logic.py:486-635  generate_all_legal_moves (+ :82-208 pseudo-legal, :234-272
+//       attack test, :275-359 uchi-fu-zume, :382-483 promotion / drop rules)
+//   shogi/shogi_move_execution.py:24-156, shogi/shogi_game.py:574-660  make_move
+//   shogi/shogi_game.py:408-450 termination, shogi_rules_logic.py:638-695 sennichite
+//   shogi/shogi_game_io.py:434-539 46-plane observation, utils/utils.py:310-336 legal mask
+//
+// The reference simulates every candidate move on a deep copy and regenerates every enemy piece's
+// moves to test for check.  This kernel computes the same legal SET with a different algorithm:
+// attack bitboards (three 27-bit words) from LDS-staged ray / step tables, an enemy attack map with
+// the king lifted off the board (king moves), checkers + pin rays (all other moves), a drop-square
+// set, and one nested reply search for the single possible uchi-fu-zume square.
+//
+// Mapping: 64 lanes cooperate on one game.  Lane = piece for attack generation and move emission,
+// lane = square for occupancy ballots / drops, lane = ray for the pin scan, and lane = 16-byte
+// chunk for the coalesced observation / mask stores.  All cross-lane traffic is wave-uniform
+// control flow + LDS, so the waves of a block never synchronise after the table load.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ksh_tables.h"
+
+#define KSH_A 13527
+#define KSH_OBSF 3726
+#define KSH_WPB 4             // waves (= games) per block
+#define KSH_MASKW 432         // dwords of the per-game legal bit-set (423 used + funnel-shift slack)
+#define KSH_M27 0x7FFFFFFu
+
+// state record byte offsets (include/keisei_hip.h, ksh_env_set_state)
+#define S_HAND 81
+#define S_SIDE 95
+#define S_MC 96
+#define S_OVER 98
+#define S_REASON 99
+#define S_WINNER 100
+#define S_HBASE 102
+
+struct KshStepArgs {
+    uint8_t *state;            // [N][128]
+    unsigned long long *hist;  // [N][hist_cap] position hashes of post-move states
+    const KshTables *tables;
+    const long long *actions;  // [N] or null (mode != 2)
+    const uint8_t *prev_mask;  // [N][A] or null
+    const uint8_t *reset_mask; // [N] or null (mode 1)
+    float *obs;                // [N][46*81]
+    uint8_t *mask;             // [N][A]
+    int *n_legal;              // [N]
+    float *reward;             // [N] (mode 2)
+    uint8_t *done;
+    uint8_t *reason;
+    signed char *winner;
+    int n_games;
+    int max_moves;
+    int hist_cap;
+    int mode;                  // 0 observe, 1 reset (masked), 2 step
+    int auto_reset;
+};
+
+struct BB3 {
+    uint32_t w0, w1, w2;
+};
+
+__device__ __forceinline__ BB3 bb_and(BB3 a, BB3 b) { return BB3{a.w0 & b.w0, a.w1 & b.w1, a.w2 & b.w2}; }
+__device__ __forceinline__ BB3 bb_or(BB3 a, BB3 b) { return BB3{a.w0 | b.w0, a.w1 | b.w1, a.w2 | b.w2}; }
+__device__ __forceinline__ BB3 bb_andn(BB3 a, BB3 b) { return BB3{a.w0 & ~b.w0, a.w1 & ~b.w1, a.w2 & ~b.w2}; }
+__device__ __forceinline__ bool bb_any(BB3 a) { return (a.w0 | a.w1 | a.w2) != 0; }
+__device__ __forceinline__ BB3 bb_zero() { return BB3{0, 0, 0}; }
+__device__ __forceinline__ int sq_word(int sq) { return (sq >= 54) ? 2 : (sq >= 27 ? 1 : 0); }
+__device__ __forceinline__ BB3 bb_sq(int sq) {
+    int w = sq_word(sq);
+    uint32_t b = 1u << (sq - 27 * w);
+    return BB3{w == 0 ? b : 0u, w == 1 ? b : 0u, w == 2 ? b : 0u};
+}
+__device__ __forceinline__ bool bb_test(BB3 a, int sq) {
+    int w = sq_word(sq);
+    uint32_t x = (w == 0) ? a.w0 : (w == 1 ? a.w1 : a.w2);
+    return (x >> (sq - 27 * w)) & 1u;
+}
+__device__ __forceinline__ BB3 bb_from_ballots(unsigned long long lo, unsigned long long hi) {
+    return BB3{(uint32_t)(lo & KSH_M27), (uint32_t)((lo >> 27) & KSH_M27),
+               (uint32_t)(((lo >> 54) | (hi << 10)) & KSH_M27)};
+}
+__device__ __forceinline__ int sq_row(int sq) { return (sq * 57) >> 9; }  // exact for 0 <= sq < 81
+
+// Squares of ray M (from its origin outwards) up to and including the nearest blocker in B = M & occ.
+__device__ __forceinline__ BB3 ray_attack(BB3 M, BB3 B, bool positive) {
+    BB3 a;
+    if (positive) {  // nearest blocker = lowest set bit; x ^ (x-1) = bits up to and including it (all ones for x = 0)
+        a.w0 = M.w0 & (B.w0 ^ (B.w0 - 1u));
+        a.w1 = B.w0 ? 0u : (M.w1 & (B.w1 ^ (B.w1 - 1u)));
+        a.w2 = (B.w0 | B.w1) ? 0u : (M.w2 & (B.w2 ^ (B.w2 - 1u)));
+    } else {         // nearest blocker = highest set bit
+        uint32_t h2 = B.w2 ? (0xFFFFFFFFu << (31 - __clz((int)B.w2))) : 0xFFFFFFFFu;
+        uint32_t h1 = B.w1 ? (0xFFFFFFFFu << (31 - __clz((int)B.w1))) : 0xFFFFFFFFu;
+        uint32_t h0 = B.w0 ? (0xFFFFFFFFu << (31 - __clz((int)B.w0))) : 0xFFFFFFFFu;
+        a.w2 = M.w2 & h2;
+        a.w1 = B.w2 ? 0u : (M.w1 & h1);
+        a.w0 = (B.w2 | B.w1) ? 0u : (M.w0 & h0);
+    }
+    return a;
+}
+// Square index of the blocker nearest to the ray origin, or -1.
+__device__ __forceinline__ int bb_nearest(BB3 B, bool positive) {
+    if (positive) {
+        if (B.w0) return __ffs((int)B.w0) - 1;
+        if (B.w1) return 27 + __ffs((int)B.w1) - 1;
+        if (B.w2) return 54 + __ffs((int)B.w2) - 1;
+        return -1;
+    }
+    if (B.w2) return 54 + 31 - __clz((int)B.w2);
+    if (B.w1) return 27 + 31 - __clz((int)B.w1);
+    if (B.w0) return 31 - __clz((int)B.w0);
+    return -1;
+}
+// Direction index from square a to square b when they share a rank, file or diagonal, else -1.
+__device__ __forceinline__ int sq_dir(int a, int b) {
+    int ra = sq_row(a), rb = sq_row(b);
+    int dr = rb - ra, dc = (b - 9 * rb) - (a - 9 * ra);
+    if (dr == 0 && dc == 0) return -1;
+    if (dr == 0) return dc < 0 ? 2 : 3;
+    if (dc == 0) return dr < 0 ? 0 : 1;
+    if (dr == dc) return dr < 0 ? 4 : 5;
+    if (dr == -dc) return dr < 0 ? 6 : 7;
+    return -1;
+}
+
+__device__ __forceinline__ uint32_t fmix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+    return x;
+}
+
+// Compiler-level ordering point for LDS traffic between lanes of ONE wave.  The hardware executes a
+// wave's DS instructions in order, so no instruction is needed; this only pins the order in the IR.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// per-wave LDS scratch
+struct KshWaveLds {
+    uint32_t maskbits[KSH_MASKW];  // legal action bit-set, bit i <-> action id i
+    uint32_t st32[32];             // the 128-byte state record
+    uint8_t plist[64];             // squares of the pieces on the board (compacted)
+    uint8_t pin_dir[96];           // per square: ray direction (from the king) it is pinned along, 0xFF none
+    uint8_t plane_of[96];          // per POV square: observation plane of the piece standing there, 0xFF none
+    float handv[16];               // hand planes: own P..R, opponent P..R
+    uint32_t red[8];               // 0-2 enemy attack map, 3 nifu files, 4 count, 5-6 hash
+};
+
+struct KshBlockLds {
+    KshTables tab;
+    KshWaveLds wave[KSH_WPB];
+};
+
+#define ST8(W) (reinterpret_cast<uint8_t *>((W).st32))
+
+__device__ __forceinline__ BB3 lds_bb(const uint32_t (*tbl)[81][4], int k, int sq) {
+    const uint32_t *p = tbl[k][sq];
+    return BB3{p[0], p[1], p[2]};
+}
+
+// ------------------------------------------------------------------------------------------------
+// Legal move generation for the side `me` on the board in W.st32.  With emit: sets the action bits in
+// W.maskbits (pawn drops on the squares in ufz_cand excluded).  Returns the number of legal moves
+// (without those pawn drops), whether `me` is in check, and ufz_cand: the pawn-drop squares whose
+// legality hinges on the uchi-fu-zume reply search (empty unless want_ufz).  In any position reachable
+// by legal play that is at most the one square in front of the enemy king; when the side NOT to
+// move is already in check (hand-made positions only) the reference's test "the king is attacked
+// after the drop" (shogi_rules_logic.py:329-332) holds for every pawn drop, so all of them are.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ksh_gen(KshBlockLds &L, KshWaveLds &W, int lane, int me, bool emit, bool want_ufz,
+                                       bool &in_check, BB3 &ufz_cand) {
+    const uint8_t *brd = ST8(W);
+    const int p0 = brd[lane];
+    const int p1 = (lane < 17) ? brd[64 + lane] : 0;
+    const bool own0 = p0 != 0 && ((p0 >= 15) == (me == 1));
+    const bool own1 = p1 != 0 && ((p1 >= 15) == (me == 1));
+    const unsigned long long occ_lo = __ballot(p0 != 0), occ_hi = __ballot(p1 != 0);
+    const BB3 occ = bb_from_ballots(occ_lo, occ_hi);
+    const BB3 own = bb_from_ballots(__ballot(own0), __ballot(own1));
+    const int myking = 1 + 7 + 14 * me, opking = 1 + 7 + 14 * (1 - me);
+    const unsigned long long k_lo = __ballot(p0 == myking), k_hi = __ballot(p1 == myking);
+    const int ksq = k_lo ? (__ffsll((long long)k_lo) - 1) : (k_hi ? 64 + __ffsll((long long)k_hi) - 1 : -1);
+    const unsigned long long e_lo = __ballot(p0 == opking), e_hi = __ballot(p1 == opking);
+    const int eksq = e_lo ? (__ffsll((long long)e_lo) - 1) : (e_hi ? 64 + __ffsll((long long)e_hi) - 1 : -1);
+    const BB3 occx = (ksq >= 0) ? bb_andn(occ, bb_sq(ksq)) : occ;  // own king lifted: enemy sliders x-ray through it
+
+    // compact the occupied squares into plist, clear the scratch
+    const int n_lo = __popcll(occ_lo);
+    const int np = n_lo + __popcll(occ_hi);
+    if (p0 != 0) W.plist[__popcll(occ_lo & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+    if (p1 != 0) W.plist[n_lo + __popcll(occ_hi & ((1ull << lane) - 1ull))] = (uint8_t)(64 + lane);
+    W.pin_dir[lane] = 0xFF;
+    if (lane < 32) W.pin_dir[64 + lane] = 0xFF;
+    if (lane < 5) W.red[lane] = 0;
+    wave_lds_sync();
+
+    // ---- lane = piece: attack set of every piece on the board
+    int sq = 0, pc = 0;
+    if (lane < np) { sq = W.plist[lane]; pc = brd[sq]; }
+    const bool has = lane < np;
+    const int color = pc >= 15 ? 1 : 0;
+    const int type = has ? (pc - 1 - 14 * color) : 7;
+    const bool mine = has && color == me;
+    const bool foe = has && color != me;
+    // step class per type (Black numbering; +4 for White's P,N,S,G), 15 = none:   P N S G B R K +P +L +N +S +B +R ; L = none
+    //   types: 0 P,1 L,2 N,3 S,4 G,5 B,6 R,7 K,8 +P,9 +L,10 +N,11 +S,12 +B,13 +R
+    const unsigned long long CLS = 0xA933338FF321F0ull;  // nibble t = class of type t
+    int cls = (int)((CLS >> (4 * type)) & 0xF);
+    if (cls < 4 && color) cls += 4;
+    // slider kind per type: 0 none, 1 lance, 2 bishop-like, 3 rook-like
+    const unsigned long long KIND = 0x32000003200010ull;
+    const int kind = has ? (int)((KIND >> (4 * type)) & 0xF) : 0;
+    const BB3 O = foe ? occx : occ;
+    BB3 att = bb_zero();
+    if (has && cls != 15) att = lds_bb(L.tab.step, cls, sq);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const bool act = kind >= 2 || (kind == 1 && i == 0);
+        const int d = kind == 3 ? i : (kind == 2 ? 4 + i : color);  // lance: Black slides N (0), White S (1)
+        if (act) {
+            BB3 M = lds_bb(L.tab.ray, d, sq);
+            att = bb_or(att, ray_attack(M, bb_and(M, O), (d & 1) != 0));
+        }
+    }
+    // enemy attack map (OR over enemy pieces) and files holding an own unpromoted pawn (nifu)
+    if (foe) {
+        if (att.w0) atomicOr(&W.red[0], att.w0);
+        if (att.w1) atomicOr(&W.red[1], att.w1);
+        if (att.w2) atomicOr(&W.red[2], att.w2);
+    }
+    if (mine && type == 0) atomicOr(&W.red[3], 1u << (sq - 9 * sq_row(sq)));
+    // checkers: enemy pieces attacking the king square
+    const unsigned long long chk = __ballot(foe && ksq >= 0 && bb_test(att, ksq));
+    const int ncheck = __popcll(chk);
+    const int csq = __shfl(sq, chk ? (__ffsll((long long)chk) - 1) : 0);
+    in_check = (ksq < 0) || ncheck > 0;  // king missing => "in check" (shogi_rules_logic.py:42-55)
+    const bool opp_in_check = __ballot(mine && eksq >= 0 && bb_test(att, eksq)) != 0ull;
+
+    // ---- lane = ray from the king: pins
+    if (lane < 8 && ksq >= 0) {
+        const int d = lane;
+        const bool pos = (d & 1) != 0;
+        BB3 M = lds_bb(L.tab.ray, d, ksq);
+        BB3 B = bb_and(M, occ);
+        const int n1 = bb_nearest(B, pos);
+        if (n1 >= 0) {
+            const int q1 = brd[n1];
+            if ((q1 >= 15) == (me == 1)) {  // nearest piece is ours: is there an enemy slider right behind it?
+                const int n2 = bb_nearest(bb_andn(B, bb_sq(n1)), pos);
+                if (n2 >= 0) {
+                    const int q2 = brd[n2];
+                    if ((q2 >= 15) != (me == 1)) {
+                        const int t2 = q2 - 1 - (q2 >= 15 ? 14 : 0);
+                        const bool slides = (d < 4) ? (t2 == 6 || t2 == 13 || (t2 == 1 && d == me))
+                                                    : (t2 == 5 || t2 == 12);
+                        if (slides) W.pin_dir[n1] = (uint8_t)d;
+                    }
+                }
+            }
+        }
+    }
+    wave_lds_sync();
+    const BB3 eatt = BB3{W.red[0], W.red[1], W.red[2]};
+    const uint32_t nifu = W.red[3];
+
+    // squares a non-king move must land on while in check; squares a drop may use
+    BB3 block = BB3{KSH_M27, KSH_M27, KSH_M27};
+    BB3 dropok = bb_andn(BB3{KSH_M27, KSH_M27, KSH_M27}, occ);
+    if (ncheck == 1) {
+        const int d = sq_dir(ksq, csq);
+        BB3 between = bb_zero();
+        if (d >= 0) between = bb_and(lds_bb(L.tab.ray, d, ksq), lds_bb(L.tab.ray, d ^ 1, csq));
+        block = bb_or(between, bb_sq(csq));
+        dropok = bb_and(dropok, between);
+    } else if (ncheck >= 2) {
+        block = bb_zero();
+        dropok = bb_zero();
+    }
+    if (ksq < 0) dropok = bb_zero();
+
+    // ---- lane = own piece: filter to legal targets, emit action ids
+    int cnt = 0;
+    if (mine && ksq >= 0) {
+        BB3 T = bb_andn(att, own);
+        if (sq == ksq) {
+            T = bb_andn(T, eatt);
+        } else {
+            T = bb_and(T, block);
+            const int pd = W.pin_dir[sq];
+            if (pd != 0xFF) T = bb_and(T, lds_bb(L.tab.ray, pd, ksq));
+        }
+        // promotion rules (shogi_rules_logic.py:382-421)
+        const bool promotable = type <= 3 || type == 5 || type == 6;
+        const int zw = me == 0 ? 0 : 2;                      // promotion-zone word
+        const BB3 zone = BB3{zw == 0 ? KSH_M27 : 0u, 0u, zw == 2 ? KSH_M27 : 0u};
+        const uint32_t last1 = me == 0 ? 0x1FFu : (0x1FFu << 18);           // last rank inside the zone word
+        const uint32_t last2 = me == 0 ? 0x3FFFFu : (0x3FFFFu << 9);        // last two ranks
+        BB3 must = bb_zero();
+        if (type == 0 || type == 1) { if (me == 0) must.w0 = last1; else must.w2 = last1; }
+        if (type == 2) { if (me == 0) must.w0 = last2; else must.w2 = last2; }
+        const bool from_zone = sq_word(sq) == zw;
+        const BB3 Tp = promotable ? (from_zone ? T : bb_and(T, zone)) : bb_zero();
+        const BB3 Tn = bb_andn(T, must);
+        cnt = __popc(Tp.w0) + __popc(Tp.w1) + __popc(Tp.w2) + __popc(Tn.w0) + __popc(Tn.w1) + __popc(Tn.w2);
+        if (emit) {
+#pragma unroll
+            for (int w = 0; w < 3; w++) {
+                uint32_t bits = w == 0 ? T.w0 : (w == 1 ? T.w1 : T.w2);
+                const uint32_t bn = w == 0 ? Tn.w0 : (w == 1 ? Tn.w1 : Tn.w2);
+                const uint32_t bp = w == 0 ? Tp.w0 : (w == 1 ? Tp.w1 : Tp.w2);
+                while (bits) {
+                    const int b = __ffs((int)bits) - 1;
+                    bits &= bits - 1u;
+                    const int to = 27 * w + b;
+                    // utils/utils.py:208-241 in closed form
+                    const int base = (sq * 80 + to - (to > sq ? 1 : 0)) * 2;
+                    if ((bn >> b) & 1u) atomicOr(&W.maskbits[base >> 5], 1u << (base & 31));
+                    if ((bp >> b) & 1u) atomicOr(&W.maskbits[(base + 1) >> 5], 1u << ((base + 1) & 31));
+                }
+            }
+        }
+    }
+
+    // ---- lane = square: drops (shogi_rules_logic.py:424-483, 562-583)
+    const uint8_t *hand = brd + S_HAND + 7 * me;
+    uint32_t ht = 0;
+#pragma unroll
+    for (int t = 0; t < 7; t++) ht |= (hand[t] != 0 ? 1u : 0u) << t;
+    ufz_cand = bb_zero();
+    if (want_ufz && (ht & 1u) && eksq >= 0) {
+        // squares where a pawn may be dropped at all: drop-ok, not the last rank, no own pawn on the file
+        const uint32_t files = (nifu & 0x1FFu) * 0x40201u;
+        BB3 pawnok = bb_andn(dropok, BB3{files, files, files});
+        if (me == 0) pawnok.w0 &= ~0x1FFu; else pawnok.w2 &= ~(0x1FFu << 18);
+        const int u = eksq + (me == 0 ? 9 : -9);  // a pawn here attacks the enemy king
+        if (opp_in_check) ufz_cand = pawnok;
+        else if (u >= 0 && u < 81) ufz_cand = bb_and(pawnok, bb_sq(u));
+    }
+    if (ht != 0) {
+        const int last_r = me == 0 ? 0 : 8, second_r = me == 0 ? 1 : 7;
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            const int s = pass * 64 + lane;
+            if (s < 81 && bb_test(dropok, s)) {
+                const int r = sq_row(s), c = s - 9 * r;
+                uint32_t f = ht;
+                if (r == last_r) f &= ~7u;          // P, L, N
+                if (r == second_r) f &= ~4u;        // N
+                if ((nifu >> c) & 1u) f &= ~1u;     // nifu
+                if (bb_test(ufz_cand, s)) f &= ~1u; // decided by the nested reply search
+                cnt += __popc(f);
+                if (emit && f) {
+                    const int bit = 12960 + 7 * s;  // utils/utils.py:253-266: 12960 + sq*7 + piece
+                    const int wd = bit >> 5, sh = bit & 31;
+                    atomicOr(&W.maskbits[wd], f << sh);
+                    if (sh > 25) atomicOr(&W.maskbits[wd + 1], f >> (32 - sh));
+                }
+            }
+        }
+    }
+    if (cnt) atomicAdd(&W.red[4], (uint32_t)cnt);
+    wave_lds_sync();
+    const int total = (int)W.red[4];
+    wave_lds_sync();
+    return total;
+}
+
+
+// Legal moves of `me` including the uchi-fu-zume decision (shogi_rules_logic.py:275-359): for every
+// candidate square drop the pawn on the LDS board, generate the opponent's replies (nested pawn drops
+// skip their own test, :461-467) and keep the drop unless it gives check AND leaves no reply.
+__device__ __forceinline__ int ksh_gen_full(KshBlockLds &L, KshWaveLds &W, int lane, int me, bool &in_check) {
+    uint8_t *st8 = ST8(W);
+    BB3 cand;
+    int n = ksh_gen(L, W, lane, me, true, true, in_check, cand);
+    for (int it = 0; it < 81 && bb_any(cand); it++) {  // wave-uniform; one iteration in reachable positions
+        const int s = bb_nearest(cand, true);
+        cand = bb_andn(cand, bb_sq(s));
+        if (lane == 0) st8[s] = (uint8_t)(1 + 14 * me);
+        wave_lds_sync();
+        bool gives_check;
+        BB3 none;
+        const int replies = ksh_gen(L, W, lane, 1 - me, false, false, gives_check, none);
+        if (lane == 0) st8[s] = 0;
+        wave_lds_sync();
+        if (!(gives_check && replies == 0)) {
+            const int bit = 12960 + 7 * s;
+            if (lane == 0) atomicOr(&W.maskbits[bit >> 5], 1u << (bit & 31));
+            n += 1;
+        }
+    }
+    wave_lds_sync();
+    return n;
+}
+
+// 64-bit key of (board, hands, side to move): the reference compares exact tuples
+// (shogi/shogi_game.py:347-372); a 2x32-bit mixed XOR key stands in for it (collision odds ~2^-64 per pair).
+__device__ __forceinline__ unsigned long long ksh_hash(KshWaveLds &W, int lane) {
+    const uint8_t *brd = ST8(W);
+    if (lane < 2) W.red[5 + lane] = 0;
+    wave_lds_sync();
+    uint32_t ha = 0, hb = 0;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const int s = pass * 64 + lane;
+        if (s < 81 && brd[s] != 0) {
+            const uint32_t key = (uint32_t)(s * 32 + brd[s]);
+            ha ^= fmix32(key * 0x9E3779B1u + 0x7F4A7C15u);
+            hb ^= fmix32((key ^ 0x5bd1e995u) * 0x2545F491u + 0x1B873593u);
+        }
+    }
+    if (lane < 14 && brd[S_HAND + lane] != 0) {
+        const uint32_t key = 0x10000u + (uint32_t)lane * 256u + brd[S_HAND + lane];
+        ha ^= fmix32(key * 0x9E3779B1u + 0x7F4A7C15u);
+        hb ^= fmix32((key ^ 0x5bd1e995u) * 0x2545F491u + 0x1B873593u);
+    }
+    if (ha) atomicXor(&W.red[5], ha);
+    if (hb) atomicXor(&W.red[6], hb);
+    wave_lds_sync();
+    unsigned long long h = ((unsigned long long)W.red[6] << 32) | W.red[5];
+    if (brd[S_SIDE]) h ^= 0xA5A5F00D5EED1234ull;
+    wave_lds_sync();
+    return h;
+}
+
+__device__ __forceinline__ float ksh_obs_value(const KshWaveLds &W, int f, float black_flag, float move_frac) {
+    const int p = (int)((unsigned)f / 81u);
+    const int s = f - 81 * p;
+    if (p < 28) return W.plane_of[s] == p ? 1.0f : 0.0f;
+    if (p < 42) return W.handv[p - 28];
+    if (p == 42) return black_flag;
+    if (p == 43) return move_frac;
+    return 0.0f;
+}
+
+extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(KshStepArgs a) {
+    __shared__ KshBlockLds L;
+    // stage the attack tables in LDS (24.8 KB, shared by the block's waves)
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.tables);
+        uint4 *dst = reinterpret_cast<uint4 *>(&L.tab);
+        for (int i = threadIdx.x; i < (int)(sizeof(KshTables) / 16); i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int g = blockIdx.x * KSH_WPB + wv;
+    if (g >= a.n_games) return;  // wave-uniform
+    KshWaveLds &W = L.wave[wv];
+    uint8_t *st8 = ST8(W);
+
+    // ---- load the state record, clear the legal bit-set
+    if (lane < 32) W.st32[lane] = reinterpret_cast<const uint32_t *>(a.state + (size_t)g * 128)[lane];
+    for (int i = lane; i < KSH_MASKW; i += 64) W.maskbits[i] = 0;
+    wave_lds_sync();
+
+    int out_done = 0, out_reason = 0, out_winner = -1, n_out = 0;
+    float out_reward = 0.0f;
+    bool need_gen = true;
+
+    if (a.mode == 1) {
+        const bool rs = a.reset_mask == nullptr || a.reset_mask[g] != 0;
+        if (rs) {
+            if (lane < 32) W.st32[lane] = reinterpret_cast<const uint32_t *>(L.tab.init_state)[lane];
+            wave_lds_sync();
+        }
+    }
+
+    int me = st8[S_SIDE];
+    if (a.mode == 2) {
+        const int mover = me;
+        const long long act = a.actions[g];
+        const bool over = st8[S_OVER] != 0;
+        if (over) {
+            // stepping a finished game (no auto-reset): nothing moves (shogi_game.py:589-593)
+            const int w = (int)st8[S_WINNER] - 1;
+            out_done = 1;
+            out_reason = st8[S_REASON];
+            out_winner = w;
+            out_reward = (w == 1 - me) ? 1.0f : (w < 0 ? 0.0f : -1.0f);
+        } else {
+            bool ok = act >= 0 && act < KSH_A;
+            if (ok && a.prev_mask != nullptr) ok = a.prev_mask[(size_t)g * KSH_A + (size_t)act] != 0;
+            int from = -1, to = 0, aux = 0;
+            if (ok) {
+                const int ai = (int)act;
+                if (ai >= 12960) {
+                    const int k = ai - 12960;
+                    to = k / 7;
+                    aux = k - 7 * to;
+                    ok = st8[to] == 0 && st8[S_HAND + 7 * mover + aux] != 0;
+                } else {
+                    const int pair = ai >> 1;
+                    aux = ai & 1;
+                    from = pair / 80;
+                    const int j = pair - 80 * from;
+                    to = j + (j >= from ? 1 : 0);
+                    const int pcf = st8[from], pct = st8[to];
+                    ok = pcf != 0 && ((pcf >= 15) == (mover == 1)) && !(pct != 0 && ((pct >= 15) == (mover == 1)));
+                    const int tf = pcf - 1 - (pcf >= 15 ? 14 : 0);
+                    if (aux && !(tf <= 3 || tf == 5 || tf == 6)) ok = false;
+                }
+            }
+            if (!ok) {
+                // the reference raises ValueError and StepManager resets the episode (step_manager.py:303-348)
+                out_done = 1;
+                out_reason = 5;
+                if (a.auto_reset) {
+                    if (lane < 32) W.st32[lane] = reinterpret_cast<const uint32_t *>(L.tab.init_state)[lane];
+                    wave_lds_sync();
+                    me = 0;
+                }
+            } else {
+                // ---- apply the move (shogi_move_execution.py:24-156); every lane computes, lane 0 writes
+                wave_lds_sync();
+                if (lane == 0) {
+                    if (from < 0) {
+                        st8[to] = (uint8_t)(1 + aux + 14 * mover);
+                        st8[S_HAND + 7 * mover + aux] -= 1;
+                    } else {
+                        const int pcf = st8[from], pct = st8[to];
+                        if (pct != 0) {
+                            int tt = pct - 1 - (pct >= 15 ? 14 : 0);
+                            if (tt >= 8) tt = (tt >= 12) ? tt - 7 : tt - 8;  // +P..+S -> P..S, +B,+R -> B,R
+                            if (tt < 7) st8[S_HAND + 7 * mover + tt] += 1;   // a captured king is not kept
+                        }
+                        int np_ = pcf;
+                        if (aux) {
+                            const int tf = pcf - 1 - 14 * mover;
+                            np_ = 1 + 14 * mover + (tf <= 3 ? tf + 8 : tf + 7);
+                        }
+                        st8[to] = (uint8_t)np_;
+                        st8[from] = 0;
+                    }
+                    const int mc = (st8[S_MC] | (st8[S_MC + 1] << 8)) + 1;
+                    st8[S_MC] = (uint8_t)(mc & 0xFF);
+                    st8[S_MC + 1] = (uint8_t)(mc >> 8);
+                    st8[S_SIDE] = (uint8_t)(1 - mover);
+                }
+                wave_lds_sync();
+                me = 1 - mover;
+                const int mc = st8[S_MC] | (st8[S_MC + 1] << 8);
+                const int hbase = st8[S_HBASE] | (st8[S_HBASE + 1] << 8);
+                // ---- position key of the post-move state, appended to the game's history
+                const unsigned long long h = ksh_hash(W, lane);
+                const int idx = mc - 1 - hbase;
+                unsigned long long *hrow = a.hist + (size_t)g * (size_t)a.hist_cap;
+                int rep = 1;
+                if (idx >= 0 && idx < a.hist_cap) {
+                    if (lane == 0) hrow[idx] = h;
+                    int matches = 0;
+                    for (int base = 0; base < idx; base += 64) {  // bounded: idx < hist_cap
+                        const int i = base + lane;
+                        const bool m = (i < idx) && hrow[i] == h;
+                        matches += __popcll(__ballot(m));
+                    }
+                    rep += matches;
+                }
+                // ---- legal moves of the side now to move (+ nested uchi-fu-zume reply search)
+                bool chk;
+                int n = ksh_gen_full(L, W, lane, me, chk);
+                need_gen = false;
+                n_out = n;
+                // ---- termination (shogi_game.py:408-450): no moves -> max moves -> sennichite
+                if (n == 0) {
+                    out_done = 1;
+                    if (chk) { out_reason = 1; out_winner = mover; out_reward = 1.0f; }
+                    else { out_reason = 2; }
+                } else if (mc >= a.max_moves) {
+                    out_done = 1;
+                    out_reason = 3;
+                } else if (rep >= 4) {
+                    out_done = 1;
+                    out_reason = 4;
+                }
+                if (out_done) {
+                    if (a.auto_reset) {
+                        if (lane < 32) W.st32[lane] = reinterpret_cast<const uint32_t *>(L.tab.init_state)[lane];
+                        for (int i = lane; i < KSH_MASKW; i += 64) W.maskbits[i] = 0;
+                        wave_lds_sync();
+                        me = 0;
+                        need_gen = true;
+                    } else if (lane == 0) {
+                        st8[S_OVER] = 1;
+                        st8[S_REASON] = (uint8_t)out_reason;
+                        st8[S_WINNER] = (uint8_t)(out_winner + 1);
+                    }
+                    wave_lds_sync();
+                }
+            }
+        }
+    }
+
+    if (need_gen) {
+        bool chk;
+        int n = ksh_gen_full(L, W, lane, me, chk);
+        n_out = n;
+    }
+    wave_lds_sync();
+    if (lane == 0) a.n_legal[g] = n_out;
+
+    // ---- write back the state and the per-game scalars
+    if (lane < 32) reinterpret_cast<uint32_t *>(a.state + (size_t)g * 128)[lane] = W.st32[lane];
+    if (a.mode == 2 && lane == 0) {
+        a.reward[g] = out_reward;
+        a.done[g] = (uint8_t)out_done;
+        a.reason[g] = (uint8_t)out_reason;
+        a.winner[g] = (signed char)out_winner;
+    }
+
+    // ---- observation (shogi_game_io.py:434-539), POV of the side to move, coalesced 16-byte stores
+    const int side = st8[S_SIDE];
+    W.plane_of[lane] = 0xFF;
+    if (lane < 32) W.plane_of[64 + lane] = 0xFF;
+    wave_lds_sync();
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const int s = pass * 64 + lane;
+        if (s < 81 && st8[s] != 0) {
+            const int pc = st8[s];
+            const int col = pc >= 15 ? 1 : 0;
+            const int t = pc - 1 - 14 * col;
+            W.plane_of[side == 0 ? s : 80 - s] = (uint8_t)((col == side ? 0 : 14) + t);
+        }
+    }
+    if (lane < 14) {
+        // planes 28-34 own hand, 35-41 opponent hand; count/18.0 in double, stored as float32 (:513-527)
+        const int cidx = lane < 7 ? side : 1 - side;
+        const int cnt = st8[S_HAND + 7 * cidx + (lane < 7 ? lane : lane - 7)];
+        W.handv[lane] = (float)((double)cnt / 18.0);
+    }
+    wave_lds_sync();
+    const float black_flag = side == 0 ? 1.0f : 0.0f;
+    const int mcount = st8[S_MC] | (st8[S_MC + 1] << 8);
+    const float move_frac = a.max_moves > 0 ? (float)((double)mcount / (double)a.max_moves) : 0.0f;
+    {
+        // row g covers global floats [g*3726, (g+1)*3726); 3726 = 2 (mod 4): even rows start on a
+        // 16-byte boundary and end with half a chunk, odd rows start with the other half.
+        float *orow = a.obs + (size_t)g * KSH_OBSF;
+        const int head = (g & 1) ? 2 : 0;  // floats before the first fully aligned chunk
+        if (head && lane == 0) {
+            float2 v = make_float2(ksh_obs_value(W, 0, black_flag, move_frac), ksh_obs_value(W, 1, black_flag, move_frac));
+            *reinterpret_cast<float2 *>(orow) = v;
+        }
+        const int nfull = (KSH_OBSF - head) >> 2;  // 931 in both cases
+        for (int c = lane; c < nfull; c += 64) {
+            const int f = head + 4 * c;
+            float4 v = make_float4(ksh_obs_value(W, f, black_flag, move_frac), ksh_obs_value(W, f + 1, black_flag, move_frac),
+                                   ksh_obs_value(W, f + 2, black_flag, move_frac), ksh_obs_value(W, f + 3, black_flag, move_frac));
+            *reinterpret_cast<float4 *>(orow + f) = v;
+        }
+        if (!head && lane == 0) {
+            const int f = 4 * nfull;  // 3724
+            float2 v = make_float2(ksh_obs_value(W, f, black_flag, move_frac), ksh_obs_value(W, f + 1, black_flag, move_frac));
+            *reinterpret_cast<float2 *>(orow + f) = v;
+        }
+    }
+
+    // ---- legal mask: expand the bit-set to one byte per action, 16-byte aligned stores
+    {
+        uint8_t *mrow = a.mask + (size_t)g * KSH_A;
+        const size_t addr = reinterpret_cast<size_t>(mrow);
+        const int head = (int)((16 - (addr & 15)) & 15);        // bytes before the first aligned chunk
+        const int nfull = (KSH_A - head) >> 4;
+        const int tail0 = head + 16 * nfull;                     // first byte of the ragged tail
+        if (lane < head) mrow[lane] = (uint8_t)((W.maskbits[0] >> lane) & 1u);
+        for (int c = lane; c < nfull; c += 64) {
+            const int b0 = head + 16 * c;
+            const uint32_t lo = W.maskbits[b0 >> 5], hi = W.maskbits[(b0 >> 5) + 1];
+            const uint32_t x = __funnelshift_r(lo, hi, b0 & 31);  // 32 bits starting at bit b0
+            uint4 v;
+            v.x = __umul24(x & 0xFu, 0x204081u) & 0x01010101u;    // 4 bits -> 4 bytes of 0/1
+            v.y = __umul24((x >> 4) & 0xFu, 0x204081u) & 0x01010101u;
+            v.z = __umul24((x >> 8) & 0xFu, 0x204081u) & 0x01010101u;
+            v.w = __umul24((x >> 12) & 0xFu, 0x204081u) & 0x01010101u;
+            *reinterpret_cast<uint4 *>(mrow + b0) = v;
+        }
+        const int ntail = KSH_A - tail0;
+        if (lane < ntail) {
+            const int b = tail0 + lane;
+            mrow[b] = (uint8_t)((W.maskbits[b >> 5] >> (b & 31)) & 1u);
+        }
+    }
+}

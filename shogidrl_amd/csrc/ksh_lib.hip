@@ -1,0 +1,266 @@
+// ksh_lib.hip -- libkeisei_hip.so: the C-ABI of include/keisei_hip.h over the gfx950 kernels.
+// Built by __graft_entry__.build() with: hipcc -O3 --offload-arch=gfx950 -shared -fPIC
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/keisei_hip.h"
+#include "ksh_env_kernel.h"
+#include "ksh_ppo_kernels.h"
+
+static thread_local std::string g_err;
+
+static int fail_hip(hipError_t e, const char *what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return KSH_E_HIP;
+}
+static int fail_arg(const char *what) {
+    g_err = what;
+    return KSH_E_ARG;
+}
+#define HIP_TRY(x)                                   \
+    do {                                             \
+        hipError_t _e = (x);                         \
+        if (_e != hipSuccess) return fail_hip(_e, #x); \
+    } while (0)
+
+struct KshEnv {
+    int device;
+    int n;
+    int max_moves;
+    int hist_cap;
+    uint8_t *state;
+    unsigned long long *hist;
+    KshTables *tables;
+};
+
+extern "C" {
+
+const char *ksh_last_error(void) { return g_err.c_str(); }
+int ksh_version(void) { return 100; }
+
+int ksh_env_create(int device, int n_games, int max_moves, void **handle) {
+    if (!handle || n_games <= 0 || max_moves <= 0 || max_moves > 65534) return fail_arg("ksh_env_create: bad argument");
+    HIP_TRY(hipSetDevice(device));
+    KshEnv *e = new KshEnv();
+    e->device = device;
+    e->n = n_games;
+    e->max_moves = max_moves;
+    e->hist_cap = max_moves + 1;
+    e->state = nullptr;
+    e->hist = nullptr;
+    e->tables = nullptr;
+    KshTables *t = new KshTables();
+    ksh_build_tables(t);
+    hipError_t err = hipMalloc(&e->state, (size_t)n_games * 128);
+    if (err == hipSuccess) err = hipMalloc(&e->hist, (size_t)n_games * e->hist_cap * sizeof(unsigned long long));
+    if (err == hipSuccess) err = hipMalloc(&e->tables, sizeof(KshTables));
+    if (err == hipSuccess) err = hipMemcpy(e->tables, t, sizeof(KshTables), hipMemcpyHostToDevice);
+    if (err == hipSuccess) {
+        std::vector<uint8_t> init((size_t)n_games * 128);
+        for (int g = 0; g < n_games; g++) memcpy(&init[(size_t)g * 128], t->init_state, 128);
+        err = hipMemcpy(e->state, init.data(), init.size(), hipMemcpyHostToDevice);
+    }
+    if (err == hipSuccess) err = hipMemset(e->hist, 0, (size_t)n_games * e->hist_cap * sizeof(unsigned long long));
+    delete t;
+    if (err != hipSuccess) {
+        if (e->state) (void)hipFree(e->state);
+        if (e->hist) (void)hipFree(e->hist);
+        if (e->tables) (void)hipFree(e->tables);
+        delete e;
+        return fail_hip(err, "ksh_env_create");
+    }
+    *handle = e;
+    return KSH_OK;
+}
+
+int ksh_env_destroy(void *handle) {
+    if (!handle) return fail_arg("ksh_env_destroy: null handle");
+    KshEnv *e = (KshEnv *)handle;
+    (void)hipFree(e->state);
+    (void)hipFree(e->hist);
+    (void)hipFree(e->tables);
+    delete e;
+    return KSH_OK;
+}
+
+int ksh_env_num_games(void *handle) { return handle ? ((KshEnv *)handle)->n : KSH_E_ARG; }
+int ksh_env_max_moves(void *handle) { return handle ? ((KshEnv *)handle)->max_moves : KSH_E_ARG; }
+
+static int launch_env(KshEnv *e, int mode, const int64_t *actions, const uint8_t *prev_mask, const uint8_t *reset_mask,
+                      float *obs, uint8_t *mask, int32_t *n_legal, float *reward, uint8_t *done, uint8_t *reason,
+                      int8_t *winner, int auto_reset, void *stream) {
+    if (!obs || !mask || !n_legal) return fail_arg("env: obs / mask / n_legal must not be null");
+    if ((reinterpret_cast<size_t>(obs) & 15) != 0) return fail_arg("env: obs must be 16-byte aligned");
+    if (mode == 2 && (!actions || !reward || !done || !reason || !winner)) return fail_arg("env step: null output");
+    KshStepArgs a;
+    a.state = e->state;
+    a.hist = e->hist;
+    a.tables = e->tables;
+    a.actions = reinterpret_cast<const long long *>(actions);
+    a.prev_mask = prev_mask;
+    a.reset_mask = reset_mask;
+    a.obs = obs;
+    a.mask = mask;
+    a.n_legal = n_legal;
+    a.reward = reward;
+    a.done = done;
+    a.reason = reason;
+    a.winner = reinterpret_cast<signed char *>(winner);
+    a.n_games = e->n;
+    a.max_moves = e->max_moves;
+    a.hist_cap = e->hist_cap;
+    a.mode = mode;
+    a.auto_reset = auto_reset;
+    const int blocks = (e->n + KSH_WPB - 1) / KSH_WPB;
+    hipLaunchKernelGGL(ksh_env_step_kernel, dim3(blocks), dim3(64 * KSH_WPB), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return KSH_OK;
+}
+
+int ksh_env_reset(void *handle, const uint8_t *reset_mask, float *obs, uint8_t *legal_mask, int32_t *n_legal,
+                  void *stream) {
+    if (!handle) return fail_arg("ksh_env_reset: null handle");
+    return launch_env((KshEnv *)handle, 1, nullptr, nullptr, reset_mask, obs, legal_mask, n_legal, nullptr, nullptr,
+                      nullptr, nullptr, 0, stream);
+}
+
+int ksh_env_observe(void *handle, float *obs, uint8_t *legal_mask, int32_t *n_legal, void *stream) {
+    if (!handle) return fail_arg("ksh_env_observe: null handle");
+    return launch_env((KshEnv *)handle, 0, nullptr, nullptr, nullptr, obs, legal_mask, n_legal, nullptr, nullptr,
+                      nullptr, nullptr, 0, stream);
+}
+
+int ksh_env_step(void *handle, const int64_t *actions, const uint8_t *prev_mask, float *next_obs, uint8_t *next_mask,
+                 int32_t *n_legal, float *reward, uint8_t *done, uint8_t *reason, int8_t *winner, int auto_reset,
+                 void *stream) {
+    if (!handle) return fail_arg("ksh_env_step: null handle");
+    return launch_env((KshEnv *)handle, 2, actions, prev_mask, nullptr, next_obs, next_mask, n_legal, reward, done,
+                      reason, winner, auto_reset, stream);
+}
+
+int ksh_env_set_state(void *handle, int game, const uint8_t *state128, void *stream) {
+    if (!handle || !state128) return fail_arg("ksh_env_set_state: null argument");
+    KshEnv *e = (KshEnv *)handle;
+    if (game < 0 || game >= e->n) return fail_arg("ksh_env_set_state: game index out of range");
+    uint8_t rec[128];
+    memset(rec, 0, sizeof rec);
+    memcpy(rec, state128, 104);
+    int pieces = 0;
+    for (int s = 0; s < 81; s++) {
+        if (rec[s] > 28) { g_err = "ksh_env_set_state: invalid piece code"; return KSH_E_STATE; }
+        pieces += rec[s] != 0;
+    }
+    if (pieces > 64) { g_err = "ksh_env_set_state: more than 64 pieces on the board"; return KSH_E_STATE; }
+    if (rec[S_SIDE] > 1) { g_err = "ksh_env_set_state: side to move must be 0 or 1"; return KSH_E_STATE; }
+    rec[S_HBASE] = rec[S_MC];  // the position history starts empty at this ply (from_sfen: shogi_game.py:320-321)
+    rec[S_HBASE + 1] = rec[S_MC + 1];
+    HIP_TRY(hipMemcpyAsync(e->state + (size_t)game * 128, rec, 128, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return KSH_OK;
+}
+
+int ksh_env_get_state(void *handle, int game, uint8_t *state128, void *stream) {
+    if (!handle || !state128) return fail_arg("ksh_env_get_state: null argument");
+    KshEnv *e = (KshEnv *)handle;
+    if (game < 0 || game >= e->n) return fail_arg("ksh_env_get_state: game index out of range");
+    HIP_TRY(hipMemcpyAsync(state128, e->state + (size_t)game * 128, 128, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return KSH_OK;
+}
+
+// ---------------------------------------------------------------------------------- PPO-side kernels
+int ksh_masked_sample(const void *logits, int logits_dtype, const uint8_t *mask, int B, uint64_t seed, uint64_t step,
+                      int deterministic, int64_t *action, float *log_prob, void *stream) {
+    if (!logits || !mask || !action || !log_prob || B <= 0) return fail_arg("ksh_masked_sample: bad argument");
+    if (logits_dtype != 0 && logits_dtype != 1) return fail_arg("ksh_masked_sample: logits_dtype must be 0 (f32) or 1 (bf16)");
+    if (logits_dtype == 0)
+        hipLaunchKernelGGL(ksh_masked_sample_kernel<float>, dim3(B), dim3(KSH_ROW_THREADS), 0, (hipStream_t)stream,
+                           (const float *)logits, mask, seed, step, deterministic, reinterpret_cast<long long *>(action), log_prob);
+    else
+        hipLaunchKernelGGL(ksh_masked_sample_kernel<ksh_bf16>, dim3(B), dim3(KSH_ROW_THREADS), 0, (hipStream_t)stream,
+                           (const ksh_bf16 *)logits, mask, seed, step, deterministic, reinterpret_cast<long long *>(action), log_prob);
+    HIP_TRY(hipGetLastError());
+    return KSH_OK;
+}
+
+int ksh_gae_scan(const float *rewards, const float *values, const uint8_t *dones, const float *last_values, double gamma,
+                 double lambda, int T, int N, float *advantages, float *returns, void *stream) {
+    if (!rewards || !values || !dones || !last_values || !advantages || !returns || T <= 0 || N <= 0)
+        return fail_arg("ksh_gae_scan: bad argument");
+    const float g = (float)gamma;             // python float -> float32 scalar (experience_buffer.py:135)
+    const float gl = (float)(gamma * lambda); // folded in double first (experience_buffer.py:138)
+    const int threads = 256;
+    hipLaunchKernelGGL(ksh_gae_kernel, dim3((N + threads - 1) / threads), dim3(threads), 0, (hipStream_t)stream, rewards,
+                       values, dones, last_values, g, gl, T, N, advantages, returns);
+    HIP_TRY(hipGetLastError());
+    return KSH_OK;
+}
+
+uint64_t ksh_ppo_loss_workspace_bytes(int B) { return (uint64_t)(B > 0 ? B : 0) * 8 * sizeof(float) + 64; }
+
+int ksh_ppo_loss_fwd_bwd(const void *logits, int logits_dtype, const uint8_t *mask, const int64_t *actions,
+                         const float *old_log_probs, const float *advantages, const float *returns, const float *values,
+                         const float *old_values, int B, float clip_eps, float vf_coef, float ent_coef, int value_clip,
+                         void *dlogits, float *dvalues, float *stats, void *workspace, void *stream) {
+    if (!logits || !mask || !actions || !old_log_probs || !advantages || !returns || !values || !dlogits || !dvalues ||
+        !stats || !workspace || B <= 0)
+        return fail_arg("ksh_ppo_loss_fwd_bwd: bad argument");
+    if (value_clip && !old_values) return fail_arg("ksh_ppo_loss_fwd_bwd: value_clip needs old_values");
+    if (logits_dtype != 0 && logits_dtype != 1) return fail_arg("ksh_ppo_loss_fwd_bwd: logits_dtype must be 0 or 1");
+    KshLossArgs a;
+    a.mask = mask;
+    a.actions = reinterpret_cast<const long long *>(actions);
+    a.old_logp = old_log_probs;
+    a.adv = advantages;
+    a.ret = returns;
+    a.values = values;
+    a.old_values = old_values;
+    a.B = B;
+    a.clip_eps = clip_eps;
+    a.vf_coef = vf_coef;
+    a.ent_coef = ent_coef;
+    a.value_clip = value_clip;
+    a.dvalues = dvalues;
+    a.stats = stats;
+    a.partial = reinterpret_cast<float *>(workspace);
+    if (logits_dtype == 0)
+        hipLaunchKernelGGL(ksh_ppo_loss_kernel<float>, dim3(B), dim3(KSH_ROW_THREADS), 0, (hipStream_t)stream, a,
+                           (const float *)logits, (float *)dlogits);
+    else
+        hipLaunchKernelGGL(ksh_ppo_loss_kernel<ksh_bf16>, dim3(B), dim3(KSH_ROW_THREADS), 0, (hipStream_t)stream, a,
+                           (const ksh_bf16 *)logits, (ksh_bf16 *)dlogits);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(ksh_ppo_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return KSH_OK;
+}
+
+// ---------------------------------------------------------------------------------- timing helpers
+int ksh_event_create(void **ev) {
+    if (!ev) return fail_arg("ksh_event_create: null");
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    *ev = (void *)e;
+    return KSH_OK;
+}
+int ksh_event_record(void *ev, void *stream) {
+    HIP_TRY(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return KSH_OK;
+}
+int ksh_event_elapsed_ms(void *start, void *stop, float *ms) {
+    if (!ms) return fail_arg("ksh_event_elapsed_ms: null");
+    HIP_TRY(hipEventSynchronize((hipEvent_t)stop));
+    HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return KSH_OK;
+}
+int ksh_event_destroy(void *ev) {
+    HIP_TRY(hipEventDestroy((hipEvent_t)ev));
+    return KSH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// ksh_tables.h -- host-side construction of the lookup tables the env kernel stages in LDS.
+//
+// Bitboard convention (device and host): a set of squares is three 27-bit words, word k holding
+// rows 3k..3k+2 (bit = sq - 27k, sq = row*9 + col, row 0 = White's back rank as in the reference,
+// shogi/shogi_game.py:83-111).  Word 0 is therefore Black's promotion zone and word 2 White's
+// (shogi_game.py:821-825).
+//
+// Ray directions d (opposite = d^1; odd d = increasing square index):
+//   0 N(-1,0) 1 S(+1,0) 2 W(0,-1) 3 E(0,+1) 4 NW(-1,-1) 5 SE(+1,+1) 6 NE(-1,+1) 7 SW(+1,-1)
+// Step classes: 0..3 Black P,N,S,G   4..7 White P,N,S,G   8 K   9 orthogonal king steps (+B extra,
+//   shogi_rules_logic.py:135-140)   10 diagonal king steps (+R extra, :129-134)
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+struct KshTables {
+    uint32_t ray[8][81][4];    // [dir][sq] -> {w0,w1,w2,0}: squares from sq (exclusive) to the edge
+    uint32_t step[11][81][4];  // [class][sq] -> {w0,w1,w2,0}
+    uint8_t init_state[128];   // packed initial position (shogi_game.py:79-130)
+    uint8_t pad[16];
+};
+static_assert(sizeof(KshTables) % 16 == 0, "tables are copied to LDS as uint4");
+
+static inline void ksh_bb_set(uint32_t *w, int sq) { w[sq / 27] |= 1u << (sq % 27); }
+
+static inline void ksh_build_tables(KshTables *t) {
+    memset(t, 0, sizeof(*t));
+    static const int DR[8] = {-1, 1, 0, 0, -1, 1, -1, 1};
+    static const int DC[8] = {0, 0, -1, 1, -1, 1, 1, -1};
+    for (int d = 0; d < 8; d++)
+        for (int sq = 0; sq < 81; sq++) {
+            int r = sq / 9 + DR[d], c = sq % 9 + DC[d];
+            while (r >= 0 && r < 9 && c >= 0 && c < 9) {
+                ksh_bb_set(t->ray[d][sq], r * 9 + c);
+                r += DR[d];
+                c += DC[d];
+            }
+        }
+    for (int cls = 0; cls < 11; cls++)
+        for (int sq = 0; sq < 81; sq++) {
+            int offs[8][2];
+            int n = 0;
+            int fw = (cls >= 4 && cls < 8) ? 1 : -1;  // White moves toward larger rows (shogi_rules_logic.py:96-98)
+            int k = (cls < 8) ? (cls & 3) : cls;
+            auto add = [&](int a, int b) { offs[n][0] = a; offs[n][1] = b; n++; };
+            if (cls < 8 && k == 0) { add(fw, 0); }
+            else if (cls < 8 && k == 1) { add(2 * fw, -1); add(2 * fw, 1); }
+            else if (cls < 8 && k == 2) { add(fw, 0); add(fw, -1); add(fw, 1); add(-fw, -1); add(-fw, 1); }
+            else if (cls < 8 && k == 3) { add(fw, 0); add(fw, -1); add(fw, 1); add(0, -1); add(0, 1); add(-fw, 0); }
+            else if (cls == 8) { for (int d = 0; d < 8; d++) add(DR[d], DC[d]); }
+            else if (cls == 9) { for (int d = 0; d < 4; d++) add(DR[d], DC[d]); }
+            else { for (int d = 4; d < 8; d++) add(DR[d], DC[d]); }
+            for (int i = 0; i < n; i++) {
+                int r = sq / 9 + offs[i][0], c = sq % 9 + offs[i][1];
+                if (r >= 0 && r < 9 && c >= 0 && c < 9) ksh_bb_set(t->step[cls][sq], r * 9 + c);
+            }
+        }
+    // initial position; piece code = 1 + type + 14*color, types P,L,N,S,G,B,R,K = 0..7
+    uint8_t *b = t->init_state;
+    static const int back[9] = {1, 2, 3, 4, 7, 4, 3, 2, 1};
+    for (int i = 0; i < 9; i++) {
+        b[2 * 9 + i] = 1 + 0 + 14;
+        b[6 * 9 + i] = 1 + 0;
+        b[0 * 9 + i] = (uint8_t)(1 + back[i] + 14);
+        b[8 * 9 + i] = (uint8_t)(1 + back[i]);
+    }
+    b[1 * 9 + 1] = 1 + 6 + 14;
+    b[1 * 9 + 7] = 1 + 5 + 14;
+    b[7 * 9 + 1] = 1 + 5;
+    b[7 * 9 + 7] = 1 + 6;
+}

@@ -1,0 +1,132 @@
+"""VecShogiEnv -- N Shogi games stepped at once on one MI355X by the hand-written HIP kernel.
+
+Host-side mirror of the reference interface for this path:
+  ShogiGame(max_moves_per_game) / reset / get_legal_moves / make_move / get_observation
+      (keisei/shogi/shogi_game.py:39-54, 113-130, 216, 574-660, 183)
+  PolicyOutputMapper.get_legal_mask (keisei/utils/utils.py:310-336)
+  the Gymnasium-style vector env the reference sketches: reset() -> obs[N];
+      step(actions[N]) -> (obs, rewards, terminated, truncated, infos) (docs/1. DESIGN.md:590-602)
+All tensors live on the GPU; nothing here synchronises with the host.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import NUM_ACTIONS, check, lib
+
+REASON_NAMES = ("Game ongoing", "Tsumi", "stalemate", "Max moves reached", "Sennichite", "illegal_move")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class VecShogiEnv:
+    def __init__(self, num_games, max_moves_per_game=500, device="cuda:0", auto_reset=True):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.KeiseiHipError("VecShogiEnv runs on an MI355X only (device=%r); there is no CPU path" % (device,))
+        self.num_games = int(num_games)
+        self.max_moves_per_game = int(max_moves_per_game)
+        self.auto_reset = bool(auto_reset)
+        self._L = lib()
+        h = _lib.C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        with torch.cuda.device(idx):
+            torch.zeros(1, device=self.device)  # make sure the HIP context exists before the library allocates
+            check(self._L.ksh_env_create(idx, self.num_games, self.max_moves_per_game, _lib.C.byref(h)), "ksh_env_create")
+        self._h = h
+        n, dev = self.num_games, self.device
+        self.obs = torch.empty((n, 46, 9, 9), dtype=torch.float32, device=dev)
+        self.legal_mask = torch.empty((n, NUM_ACTIONS), dtype=torch.bool, device=dev)
+        self.n_legal = torch.empty(n, dtype=torch.int32, device=dev)
+        self.reward = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.done = torch.zeros(n, dtype=torch.bool, device=dev)
+        self.reason = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.winner = torch.zeros(n, dtype=torch.int8, device=dev)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ksh_env_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def seed(self, seed_value=None):
+        """No-op like ShogiGame.seed (shogi_game.py:56-73): the env is deterministic given the actions."""
+        self._seed_value = seed_value
+        return self
+
+    # ------------------------------------------------------------------ API
+    def reset(self, reset_mask=None):
+        """Reset all games (or those where reset_mask is True). Returns (obs, legal_mask)."""
+        rm = None
+        if reset_mask is not None:
+            rm = reset_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        check(self._L.ksh_env_reset(self._h, rm.data_ptr() if rm is not None else None, self.obs.data_ptr(),
+                                    self.legal_mask.data_ptr(), self.n_legal.data_ptr(), _stream()), "ksh_env_reset")
+        return self.obs, self.legal_mask
+
+    def observe(self):
+        check(self._L.ksh_env_observe(self._h, self.obs.data_ptr(), self.legal_mask.data_ptr(), self.n_legal.data_ptr(),
+                                      _stream()), "ksh_env_observe")
+        return self.obs, self.legal_mask
+
+    def step(self, actions, validate=True, out_obs=None, out_mask=None):
+        """actions: int64 [N] on the device. Returns (obs, reward, terminated, truncated, info)."""
+        if actions.dtype != torch.int64 or actions.device != self.device or actions.numel() != self.num_games:
+            raise ValueError("actions must be an int64 tensor of shape [%d] on %s" % (self.num_games, self.device))
+        actions = actions.contiguous()
+        obs = self.obs if out_obs is None else out_obs
+        mask = self.legal_mask if out_mask is None else out_mask
+        prev = self.legal_mask.data_ptr() if validate else None
+        check(self._L.ksh_env_step(self._h, actions.data_ptr(), prev, obs.data_ptr(), mask.data_ptr(),
+                                   self.n_legal.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(),
+                                   self.reason.data_ptr(), self.winner.data_ptr(), int(self.auto_reset), _stream()),
+              "ksh_env_step")
+        if out_mask is not None:
+            self.legal_mask = out_mask
+        if out_obs is not None:
+            self.obs = out_obs
+        truncated = self.reason == 3
+        terminated = self.done & ~truncated
+        info = {"reason": self.reason, "winner": self.winner, "n_legal": self.n_legal, "done": self.done}
+        return obs, self.reward, terminated, truncated, info
+
+    # ------------------------------------------------------------------ host-side state exchange (tests / fixtures)
+    def set_state(self, game, rec128):
+        rec = np.ascontiguousarray(rec128, np.uint8)
+        assert rec.size >= 104
+        buf = np.zeros(128, np.uint8)
+        buf[:rec.size] = rec[:128]
+        check(self._L.ksh_env_set_state(self._h, int(game), buf.ctypes.data, _stream()), "ksh_env_set_state")
+
+    def get_state(self, game):
+        buf = np.zeros(128, np.uint8)
+        check(self._L.ksh_env_get_state(self._h, int(game), buf.ctypes.data, _stream()), "ksh_env_get_state")
+        return buf
+
+
+class DeviceTimer:
+    """hipEvent pair on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self._L = lib()
+        self.a, self.b = _lib.C.c_void_p(), _lib.C.c_void_p()
+        check(self._L.ksh_event_create(_lib.C.byref(self.a)), "ksh_event_create")
+        check(self._L.ksh_event_create(_lib.C.byref(self.b)), "ksh_event_create")
+
+    def start(self):
+        check(self._L.ksh_event_record(self.a, _stream()), "ksh_event_record")
+
+    def stop(self):
+        check(self._L.ksh_event_record(self.b, _stream()), "ksh_event_record")
+
+    def elapsed_ms(self):
+        ms = _lib.C.c_float()
+        check(self._L.ksh_event_elapsed_ms(self.a, self.b, _lib.C.byref(ms)), "ksh_event_elapsed_ms")
+        return float(ms.value)

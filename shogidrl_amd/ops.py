@@ -1,0 +1,112 @@
+"""Learner-side operators over the HIP kernels (no torch fallbacks).
+
+  masked_sample   <- BaseActorCriticModel.get_action_and_value tail (keisei/core/base_actor_critic.py:64-116)
+  gae             <- ExperienceBuffer.compute_advantages_and_returns (keisei/core/experience_buffer.py:99-145)
+  ppo_loss        <- evaluate_actions tail + PPOAgent.learn loss lines (base_actor_critic.py:147-184,
+                     keisei/core/ppo_agent.py:340-383), forward and backward fused in one kernel
+"""
+import torch
+
+from ._lib import NUM_ACTIONS, KeiseiHipError, check, lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and t.device.type != "cuda":
+            raise KeiseiHipError("shogidrl_amd ops run on an MI355X only; got a %s tensor (no CPU path)" % t.device)
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    raise TypeError("logits must be float32 or bfloat16, got %s" % t.dtype)
+
+
+def _mask_u8(mask):
+    if mask.dtype not in (torch.bool, torch.uint8):
+        raise TypeError("legal mask must be bool or uint8")
+    return mask.contiguous()
+
+
+def masked_sample(logits, legal_mask, seed, step, deterministic=False):
+    """logits [B,13527] f32|bf16, legal_mask [B,13527] bool -> (action int64 [B], log_prob f32 [B])."""
+    _need_cuda(logits, legal_mask)
+    B = logits.shape[0]
+    assert logits.shape == (B, NUM_ACTIONS) and legal_mask.shape == (B, NUM_ACTIONS)
+    logits = logits.contiguous()
+    legal_mask = _mask_u8(legal_mask)
+    action = torch.empty(B, dtype=torch.int64, device=logits.device)
+    logp = torch.empty(B, dtype=torch.float32, device=logits.device)
+    check(lib().ksh_masked_sample(logits.data_ptr(), _dtype_code(logits), legal_mask.data_ptr(), B, int(seed), int(step),
+                                  int(bool(deterministic)), action.data_ptr(), logp.data_ptr(), _stream()),
+          "ksh_masked_sample")
+    return action, logp
+
+
+def gae(rewards, values, dones, last_values, gamma, lam):
+    """[T,N] float32 rewards/values, [T,N] bool dones, [N] last_values -> (advantages, returns) [T,N]."""
+    _need_cuda(rewards, values, dones, last_values)
+    T, N = rewards.shape
+    rewards = rewards.contiguous().float()
+    values = values.contiguous().float()
+    dones = dones.contiguous()
+    if dones.dtype not in (torch.bool, torch.uint8):
+        raise TypeError("dones must be bool or uint8")
+    last_values = last_values.contiguous().float()
+    adv = torch.empty_like(rewards)
+    ret = torch.empty_like(rewards)
+    check(lib().ksh_gae_scan(rewards.data_ptr(), values.data_ptr(), dones.data_ptr(), last_values.data_ptr(),
+                             float(gamma), float(lam), T, N, adv.data_ptr(), ret.data_ptr(), _stream()), "ksh_gae_scan")
+    return adv, ret
+
+
+class _PPOLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, values, legal_mask, actions, old_log_probs, advantages, returns, old_values, clip_eps,
+                vf_coef, ent_coef, value_clip):
+        _need_cuda(logits, values, legal_mask)
+        B = logits.shape[0]
+        logits_c = logits.contiguous()
+        values_c = values.contiguous().float()
+        mask = _mask_u8(legal_mask)
+        f = lambda t: t.contiguous().float()
+        dlogits = torch.empty_like(logits_c)
+        dvalues = torch.empty(B, dtype=torch.float32, device=logits.device)
+        stats = torch.empty(8, dtype=torch.float32, device=logits.device)
+        L = lib()
+        ws = torch.empty(int(L.ksh_ppo_loss_workspace_bytes(B)), dtype=torch.uint8, device=logits.device)
+        ov = f(old_values) if old_values is not None else None
+        check(L.ksh_ppo_loss_fwd_bwd(logits_c.data_ptr(), _dtype_code(logits_c), mask.data_ptr(),
+                                     actions.contiguous().data_ptr(), f(old_log_probs).data_ptr(), f(advantages).data_ptr(),
+                                     f(returns).data_ptr(), values_c.data_ptr(), ov.data_ptr() if ov is not None else None,
+                                     B, float(clip_eps), float(vf_coef), float(ent_coef), int(bool(value_clip)),
+                                     dlogits.data_ptr(), dvalues.data_ptr(), stats.data_ptr(), ws.data_ptr(), _stream()),
+              "ksh_ppo_loss_fwd_bwd")
+        ctx.save_for_backward(dlogits, dvalues)
+        ctx.values_dtype = values.dtype
+        ctx.mark_non_differentiable(stats)
+        return stats[0].clone(), stats
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_stats):
+        dlogits, dvalues = ctx.saved_tensors
+        return (dlogits * grad_loss.to(dlogits.dtype), (dvalues * grad_loss).to(ctx.values_dtype),
+                None, None, None, None, None, None, None, None, None, None)
+
+
+def ppo_loss(logits, values, legal_mask, actions, old_log_probs, advantages, returns, old_values=None,
+             clip_eps=0.2, vf_coef=0.5, ent_coef=0.01, value_clip=False):
+    """Returns (loss, stats) with stats = [loss, policy_loss, value_loss, entropy_loss(-mean H), kl, clip_frac, 0, 0].
+    `loss` is differentiable w.r.t. logits and values (gradients come from the fused kernel)."""
+    if value_clip and old_values is None:
+        raise ValueError("value_clip=True needs old_values")
+    if actions.dtype != torch.int64:
+        raise TypeError("actions must be int64")
+    return _PPOLossFn.apply(logits, values, legal_mask, actions, old_log_probs, advantages, returns, old_values,
+                            clip_eps, vf_coef, ent_coef, value_clip)

@@ -1,0 +1,124 @@
+"""TEST INFRASTRUCTURE: Python driver of the host-emulated env kernel (tests/emu/libksh_emu.so)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+A = 13527
+
+
+def _lib():
+    subprocess.check_call(["make", "-C", _DIR, "-s"])
+    L = C.CDLL(os.path.join(_DIR, "libksh_emu.so"))
+    L.emu_env_launch.argtypes = [C.c_void_p] * 13 + [C.c_int] * 5
+    L.emu_build_tables.argtypes = [C.c_void_p]
+    return L
+
+
+class EmuEnv:
+    def __init__(self, n, max_moves=500):
+        self.L = _lib()
+        self.n, self.max_moves = n, max_moves
+        self.cap = max_moves + 1
+        self.tables = np.zeros(self.L.emu_tables_size(), np.uint8)
+        self.L.emu_build_tables(self.tables.ctypes.data)
+        self.state = np.zeros((n, 128), np.uint8)
+        self.hist = np.zeros((n, self.cap), np.uint64)
+        self.obs = np.zeros((n, 46, 9, 9), np.float32)
+        self.mask = np.zeros((n, A), np.uint8)
+        self.n_legal = np.zeros(n, np.int32)
+        self.reward = np.zeros(n, np.float32)
+        self.done = np.zeros(n, np.uint8)
+        self.reason = np.zeros(n, np.uint8)
+        self.winner = np.zeros(n, np.int8)
+
+    def _launch(self, mode, actions=None, prev_mask=None, reset_mask=None, auto_reset=1):
+        p = lambda x: None if x is None else x.ctypes.data
+        self.obs[:] = -7.0          # poison: every byte must be rewritten
+        self.mask[:] = 0xCC
+        self.L.emu_env_launch(p(self.state), p(self.hist), p(self.tables), p(actions), p(prev_mask), p(reset_mask),
+                              p(self.obs), p(self.mask), p(self.n_legal), p(self.reward), p(self.done),
+                              p(self.reason), p(self.winner), self.n, self.max_moves, self.cap, mode, auto_reset)
+
+    def reset(self, reset_mask=None):
+        rm = None if reset_mask is None else np.ascontiguousarray(reset_mask, np.uint8)
+        self._launch(1, reset_mask=rm)
+        return self.obs.copy(), self.mask.copy(), self.n_legal.copy()
+
+    def observe(self):
+        self._launch(0)
+        return self.obs.copy(), self.mask.copy(), self.n_legal.copy()
+
+    def step(self, actions, auto_reset=True, check_prev=True):
+        a = np.ascontiguousarray(actions, np.int64)
+        pm = self.mask.copy() if check_prev else None
+        self._launch(2, actions=a, prev_mask=pm, auto_reset=int(auto_reset))
+        return (self.obs.copy(), self.mask.copy(), self.n_legal.copy(), self.reward.copy(), self.done.copy(),
+                self.reason.copy(), self.winner.copy())
+
+    def set_state(self, g, rec128):
+        rec = np.array(rec128, np.uint8).copy()
+        mc = int(rec[96]) | (int(rec[97]) << 8)
+        rec[102], rec[103] = mc & 0xFF, mc >> 8      # history starts empty at this ply
+        self.state[g] = rec
+
+
+# ------------------------------------------------------------------ learner-side kernels
+def _plib():
+    L = _lib()
+    L.emu_gae.argtypes = [C.c_void_p] * 4 + [C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.emu_masked_sample.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int,
+                                    C.c_void_p, C.c_void_p]
+    L.emu_ppo_loss.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_float, C.c_float, C.c_float,
+                                                                          C.c_int] + [C.c_void_p] * 4
+    return L
+
+
+def to_bf16_bits(x):
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def from_bf16_bits(b):
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+class EmuOps:
+    """numpy front-end with the same call shapes as tests use for the HIP library."""
+
+    def gae(self, r, v, d, last_v, gamma, lam):
+        r = np.ascontiguousarray(r, np.float32); v = np.ascontiguousarray(v, np.float32)
+        d = np.ascontiguousarray(d, np.uint8); lv = np.ascontiguousarray(last_v, np.float32)
+        T, N = r.shape
+        adv = np.zeros((T, N), np.float32); ret = np.zeros((T, N), np.float32)
+        _plib().emu_gae(r.ctypes.data, v.ctypes.data, d.ctypes.data, lv.ctypes.data, gamma, lam, T, N,
+                        adv.ctypes.data, ret.ctypes.data)
+        return adv, ret
+
+    def masked_sample(self, logits, mask, seed, step, deterministic, bf16=False, offset=0):
+        B = logits.shape[0]
+        lg = to_bf16_bits(logits) if bf16 else np.ascontiguousarray(logits, np.float32)
+        # `offset` shifts the buffers by that many elements to exercise every alignment phase
+        buf = np.zeros(lg.size + 16, lg.dtype); buf[offset:offset + lg.size] = lg.ravel()
+        mb = np.zeros(mask.size + 16, np.uint8); mb[offset:offset + mask.size] = mask.astype(np.uint8).ravel()
+        act = np.zeros(B, np.int64); lp = np.zeros(B, np.float32)
+        _plib().emu_masked_sample(buf.ctypes.data + offset * buf.itemsize, int(bf16), mb.ctypes.data + offset, B,
+                                  seed, step, int(deterministic), act.ctypes.data, lp.ctypes.data)
+        return act, lp
+
+    def ppo_loss(self, logits, mask, actions, old_logp, adv, ret, values, old_values, clip_eps, vf, ent, value_clip,
+                 bf16=False):
+        B = logits.shape[0]
+        lg = to_bf16_bits(logits) if bf16 else np.ascontiguousarray(logits, np.float32)
+        m8 = np.ascontiguousarray(mask, np.uint8)
+        dl = np.full(lg.shape, 0x7FC1 if bf16 else np.nan, lg.dtype)
+        f = lambda x: np.ascontiguousarray(x, np.float32)
+        a64 = np.ascontiguousarray(actions, np.int64)
+        ol, ad, rt, vl, ov = f(old_logp), f(adv), f(ret), f(values), f(old_values)
+        dv = np.zeros(B, np.float32); st = np.zeros(8, np.float32); ws = np.zeros(B * 8 + 16, np.float32)
+        _plib().emu_ppo_loss(lg.ctypes.data, int(bf16), m8.ctypes.data, a64.ctypes.data, ol.ctypes.data, ad.ctypes.data,
+                             rt.ctypes.data, vl.ctypes.data, ov.ctypes.data, B, clip_eps, vf, ent, int(value_clip),
+                             dl.ctypes.data, dv.ctypes.data, st.ctypes.data, ws.ctypes.data)
+        return (from_bf16_bits(dl) if bf16 else dl), dv, st

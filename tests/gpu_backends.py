@@ -1,0 +1,87 @@
+"""Adapters that expose the PRODUCT (shogidrl_amd over the C-ABI of libkeisei_hip.so, on cuda:0) through
+the numpy backend protocols of tests/envcheck.py and tests/ppocheck.py."""
+import numpy as np
+import torch
+
+from shogidrl_amd import ops
+from shogidrl_amd.env import VecShogiEnv
+
+DEV = "cuda:0"
+
+
+class GpuEnv:
+    def __init__(self, n, max_moves):
+        self.n = n
+        self.env = VecShogiEnv(n, max_moves, device=DEV)
+
+    def _out(self):
+        e = self.env
+        torch.cuda.synchronize()
+        return e.obs.cpu().numpy().copy(), e.legal_mask.cpu().numpy().astype(np.uint8), e.n_legal.cpu().numpy().copy()
+
+    def reset(self, reset_mask=None):
+        rm = None if reset_mask is None else torch.as_tensor(np.asarray(reset_mask, np.uint8), device=DEV)
+        self.env.obs.fill_(-7.0)
+        self.env.legal_mask.view(torch.uint8).fill_(0xCC)
+        self.env.reset(rm)
+        return self._out()
+
+    def observe(self):
+        self.env.obs.fill_(-7.0)
+        self.env.legal_mask.view(torch.uint8).fill_(0xCC)
+        self.env.observe()
+        return self._out()
+
+    def step(self, actions, auto_reset=True, check_prev=True):
+        e = self.env
+        e.auto_reset = bool(auto_reset)
+        a = torch.as_tensor(np.asarray(actions, np.int64), device=DEV)
+        if check_prev:
+            # validate against the mask the previous call produced, writing the new one elsewhere
+            new_mask = torch.full_like(e.legal_mask.view(torch.uint8), 0xCC).view(torch.bool)
+            new_obs = torch.full_like(e.obs, -7.0)
+            e.step(a, validate=True, out_obs=new_obs, out_mask=new_mask)
+        else:
+            e.step(a, validate=False)
+        torch.cuda.synchronize()
+        obs, mask, nl = self._out()
+        return (obs, mask, nl, e.reward.cpu().numpy().copy(), e.done.cpu().numpy().astype(np.uint8),
+                e.reason.cpu().numpy().copy(), e.winner.cpu().numpy().copy())
+
+    def set_state(self, g, rec128):
+        self.env.set_state(g, rec128)
+
+
+def make_env(n, max_moves):
+    return GpuEnv(n, max_moves)
+
+
+class GpuOps:
+    def gae(self, r, v, d, last_v, gamma, lam):
+        t = lambda x, dt: torch.as_tensor(np.ascontiguousarray(x, dt), device=DEV)
+        adv, ret = ops.gae(t(r, np.float32), t(v, np.float32), t(d, np.uint8), t(last_v, np.float32), gamma, lam)
+        return adv.cpu().numpy(), ret.cpu().numpy()
+
+    def masked_sample(self, logits, mask, seed, step, deterministic, bf16=False, offset=0):
+        B, A = logits.shape
+        dt = torch.bfloat16 if bf16 else torch.float32
+        flat = torch.zeros(B * A + 16, dtype=dt, device=DEV)
+        flat[offset:offset + B * A] = torch.as_tensor(logits, device=DEV).to(dt).reshape(-1)
+        mflat = torch.zeros(B * A + 16, dtype=torch.uint8, device=DEV)
+        mflat[offset:offset + B * A] = torch.as_tensor(np.asarray(mask, np.uint8), device=DEV).reshape(-1)
+        lg = flat[offset:offset + B * A].view(B, A)       # views keep the (mis)alignment of the slice start
+        mk = mflat[offset:offset + B * A].view(B, A)
+        act, lp = ops.masked_sample(lg, mk, seed, step, deterministic)
+        return act.cpu().numpy(), lp.cpu().numpy()
+
+    def ppo_loss(self, logits, mask, actions, old_logp, adv, ret, values, old_values, clip_eps, vf, ent, value_clip,
+                 bf16=False):
+        dt = torch.bfloat16 if bf16 else torch.float32
+        lg = torch.as_tensor(logits, device=DEV).to(dt).requires_grad_(True)
+        vl = torch.as_tensor(np.asarray(values, np.float32), device=DEV).requires_grad_(True)
+        t = lambda x: torch.as_tensor(np.asarray(x, np.float32), device=DEV)
+        loss, stats = ops.ppo_loss(lg, vl, torch.as_tensor(np.asarray(mask, bool), device=DEV),
+                                   torch.as_tensor(np.asarray(actions, np.int64), device=DEV), t(old_logp), t(adv), t(ret),
+                                   t(old_values), clip_eps, vf, ent, bool(value_clip))
+        loss.backward()
+        return lg.grad.float().cpu().numpy(), vl.grad.cpu().numpy(), stats.cpu().numpy()

@@ -1,0 +1,37 @@
+"""The env kernel source (shogidrl_amd/csrc/ksh_env_kernel.h) executed on the HOST through the fiber
+emulator in tests/emu, checked against the golden vectors and the oracle.  This exercises the kernel's
+logic (bitboards, pins, drops, uchi-fu-zume, termination, encoders) without a GPU; the same checks
+run against the real HIP library in tests/test_gpu_env.py."""
+import numpy as np
+
+from tests import envcheck
+from tests.emu.emu import EmuEnv
+
+
+def make_env(n, max_moves):
+    return EmuEnv(n, max_moves)
+
+
+def test_emu_positions_fixture():
+    assert envcheck.check_positions(make_env) > 500
+
+
+def test_emu_sequences_fixture():
+    assert envcheck.check_sequences(make_env) > 80
+
+
+def test_emu_traces_fixture():
+    assert envcheck.check_traces(make_env) > 15000
+
+
+def test_emu_traces_no_autoreset_terminal_obs():
+    assert envcheck.check_traces(make_env, max_games=6, auto_reset=False) > 1000
+
+
+def test_emu_random_vs_oracle_drop_heavy():
+    envcheck.check_random_vs_oracle(make_env, n_games=24, n_steps=220, seed=5, drop_bias=0.5)
+
+
+def test_emu_random_short_games_many_resets():
+    ndone = envcheck.check_random_vs_oracle(make_env, n_games=16, n_steps=150, seed=9, max_moves=40)
+    assert ndone >= 16 * 3

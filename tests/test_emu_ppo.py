@@ -1,0 +1,45 @@
+"""Learner-side kernel sources (shogidrl_amd/csrc/ksh_ppo_kernels.h) executed on the HOST through the
+fiber emulator, checked against golden vectors from the reference and against the oracle."""
+import pytest
+
+from tests import ppocheck
+from tests.emu.emu import EmuOps
+
+ops = EmuOps()
+
+
+def test_oracle_ppo_loss_pinned_to_reference_autograd():
+    ppocheck.check_oracle_loss_golden()
+
+
+def test_emu_gae_golden_bit_exact():
+    ppocheck.check_gae_golden(ops)
+
+
+def test_emu_gae_vs_oracle_batched():
+    ppocheck.check_gae_vs_oracle(ops, T=37, N=300, seed=3)
+
+
+def test_emu_ppo_loss_golden():
+    ppocheck.check_loss_golden(ops)
+
+
+@pytest.mark.parametrize("B,vc,dense,empty", [(5, 0, 0, 0), (7, 1, 1, 1), (3, 0, 0, 3)])
+def test_emu_ppo_loss_vs_oracle(B, vc, dense, empty):
+    ppocheck.check_loss_vs_oracle(ops, B, seed=B, value_clip=vc, dense_rows=dense, empty_rows=empty)
+
+
+def test_emu_ppo_loss_bf16():
+    ppocheck.check_loss_vs_oracle(ops, 4, seed=21, bf16=True)
+
+
+def test_emu_sample_golden():
+    ppocheck.check_sample_golden(ops)
+
+
+def test_emu_sample_bf16():
+    ppocheck.check_sample_bf16(ops)
+
+
+def test_emu_sample_distribution():
+    ppocheck.check_sample_distribution(ops, n_draws=2000)

@@ -1,0 +1,79 @@
+"""Parity tests proper: the HIP env kernel on a real MI355X, called through the C-ABI, against the
+golden vectors from the reference and against the oracle on seeded self-play."""
+import numpy as np
+import pytest
+
+from tests import envcheck
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def make_env():
+    from tests.gpu_backends import make_env as mk
+    return mk
+
+
+def test_gpu_positions_fixture(make_env):
+    assert envcheck.check_positions(make_env) > 500
+
+
+def test_gpu_sequences_fixture(make_env):
+    assert envcheck.check_sequences(make_env) > 80
+
+
+def test_gpu_traces_fixture(make_env):
+    assert envcheck.check_traces(make_env) > 15000
+
+
+def test_gpu_traces_no_autoreset_terminal_obs(make_env):
+    assert envcheck.check_traces(make_env, max_games=6, auto_reset=False) > 1000
+
+
+def test_gpu_random_vs_oracle_256_games(make_env):
+    # BASELINE.json configs[1]: 256 batched self-play games, bit-exact masks / obs / terminations
+    envcheck.check_random_vs_oracle(make_env, n_games=256, n_steps=160, seed=1)
+
+
+def test_gpu_random_vs_oracle_drop_heavy(make_env):
+    envcheck.check_random_vs_oracle(make_env, n_games=64, n_steps=260, seed=5, drop_bias=0.5)
+
+
+def test_gpu_random_short_games_many_resets(make_env):
+    ndone = envcheck.check_random_vs_oracle(make_env, n_games=67, n_steps=150, seed=9, max_moves=40)
+    assert ndone >= 67 * 3
+
+
+def test_gpu_full_size_4096_properties():
+    """BASELINE.json's 4096-game size through size-independent properties: every mask row is a 0/1 row whose
+    population equals n_legal, every observation is a valid one-hot board of the side to move, identical
+    action streams give identical outputs (determinism), and a 64-game sample agrees with the oracle."""
+    import torch
+    from oracle import ko
+    from shogidrl_amd.env import VecShogiEnv
+    N = 4096
+    envs = [VecShogiEnv(N, 500), VecShogiEnv(N, 500)]
+    for e in envs:
+        e.reset()
+    ora = ko.VecGames(64, 500)
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    for k in range(40):
+        m = envs[0].legal_mask
+        u8 = m.view(torch.uint8)
+        assert int(u8.max()) <= 1
+        assert torch.equal(u8.sum(dim=1).to(torch.int32), envs[0].n_legal)
+        w = torch.rand(m.shape, device=m.device, generator=g) * m
+        a = w.argmax(dim=1)
+        assert bool(m.gather(1, a[:, None]).all())
+        for e in envs:
+            e.step(a)
+        assert torch.equal(envs[0].obs, envs[1].obs) and torch.equal(envs[0].legal_mask, envs[1].legal_mask)
+        obs = envs[0].obs
+        board = obs[:, :28]
+        assert bool(((board == 0) | (board == 1)).all())
+        assert bool((board.sum(dim=1) <= 1).all())              # at most one piece per square
+        assert bool((obs[:, 44:] == 0).all())
+        o = ora.step(a[:64].cpu().numpy(), auto_reset=True)
+        assert np.array_equal(obs[:64].cpu().numpy(), o[0])
+        assert np.array_equal(envs[0].legal_mask[:64].cpu().numpy().astype(np.uint8), o[1])
+        assert np.array_equal(envs[0].done[:64].cpu().numpy().astype(np.uint8), o[4])

@@ -1,0 +1,34 @@
+"""Scratch micro-benchmark of the env kernel (random legal self-play). Superseded by bench.py."""
+import sys
+import time
+
+import torch
+
+from shogidrl_amd import ops
+from shogidrl_amd.env import DeviceTimer, VecShogiEnv
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+env = VecShogiEnv(N, 500)
+env.reset()
+logits = torch.zeros(N, 13527, device="cuda:0")
+acts = []
+# pre-generate nothing: actions depend on state; time env kernel alone with events around each launch
+tm = DeviceTimer()
+tot_env = 0.0
+for t in range(64):
+    a, _ = ops.masked_sample(logits, env.legal_mask, 42, t)
+    env.step(a)
+torch.cuda.synchronize()
+t0 = time.time()
+for t in range(steps):
+    a, _ = ops.masked_sample(logits, env.legal_mask, 42, 64 + t)
+    tm.start()
+    env.step(a, validate=False)
+    tm.stop()
+    tot_env += tm.elapsed_ms()
+torch.cuda.synchronize()
+wall = time.time() - t0
+ms = tot_env / steps
+print("N=%d env kernel %.3f ms/step -> %.1f M env-steps/s ; %.1f GB/s of 28710 B/step; loop wall %.3f ms/step" %
+      (N, ms, N / ms / 1e3, N * 28710 / ms / 1e6, wall / steps * 1e3))
