@@ -26,6 +26,8 @@ typedef __bf16 ksh_bf16;
 extern "C" __global__ void ksh_gae_kernel(const float *__restrict__ r, const float *__restrict__ v,
                                           const uint8_t *__restrict__ d, const float *__restrict__ last_v, float g,
                                           float gl, int T, int N, float *__restrict__ adv, float *__restrict__ ret) {
+    // hipcc contracts a*b+c into one FMA by default; the reference rounds after every operation.
+#pragma clang fp contract(off)
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     float gae = 0.0f;
@@ -34,10 +36,17 @@ extern "C" __global__ void ksh_gae_kernel(const float *__restrict__ r, const flo
         const size_t i = (size_t)t * (size_t)N + (size_t)n;
         const float vi = v[i];
         const float m = d[i] ? 0.0f : 1.0f;                                  // 1.0 - done
-        const float delta = __fsub_rn(__fadd_rn(r[i], __fmul_rn(__fmul_rn(g, next_v), m)), vi);
-        gae = __fadd_rn(delta, __fmul_rn(__fmul_rn(gl, m), gae));
+        // plain operators under the pragma: the __f*_rn wrappers are inlined with their own
+        // (contractable) flags and would be fused back into v_fmac_f32
+        const float a1 = g * next_v;
+        const float a2 = a1 * m;
+        const float a3 = r[i] + a2;
+        const float delta = a3 - vi;
+        const float b1 = gl * m;
+        const float b2 = b1 * gae;
+        gae = delta + b2;
         adv[i] = gae;
-        ret[i] = __fadd_rn(gae, vi);
+        ret[i] = gae + vi;
         next_v = vi;
     }
 }
