@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- the driver's benchmark contract for the Keisei self-play + PPO hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = one full pass of the hot path over one batch: a rollout of T plies for every game of the
+batch (policy forward -> masked sample kernel -> env step kernel, next obs / mask written in place), the
+GAE scan, and the PPO update (ppo_epochs x minibatches: forward, fused PPO-loss kernel fwd+bwd, backward,
+gradient all-reduce, clip, Adam).  Workload = BASELINE.json configs[2]: 4096 batched self-play games per
+GPU, ResNet 9x256 + SE 0.25 actor-critic (13.24 M parameters, random init), bf16 autocast tower, synthetic
+self-play data (games start from the standard position; there is no dataset on this path).
+
+`value` = env-steps/s of the WHOLE job (all ranks, rollout + update), i.e. the "steps per second" the
+reference displays (keisei/training/training_loop_manager.py:609-616).  The same JSON line carries the
+phase rates (self-play env-steps/s, PPO samples/s), the roofline of the dominant hand-written kernel
+(ksh_env_step_kernel, HBM-bound) measured live with hipEvents on the launch stream, and the CPU baseline
+(the oracle = port of the reference's algorithm, timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+ENV_BYTES_PER_STEP = 28710       # obs 14 904 + mask 13 527 + state/scalars 279
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--games", type=int, default=4096, help="games per GPU")
+    ap.add_argument("--rollout", type=int, default=32, help="plies per game per step (T)")
+    ap.add_argument("--epochs", type=int, default=10, help="ppo_epochs (reference default 10)")
+    ap.add_argument("--minibatch", type=int, default=4096, help="GPU-sized minibatch (reference default 64)")
+    ap.add_argument("--depth", type=int, default=9)
+    ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--replay", type=int, default=96, help="env launches in the roofline replay")
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds):
+    """The oracle (plain-C port of the reference's algorithm) on ONE host core, bounded sample."""
+    import numpy as np
+    from oracle import ko
+    n = 16
+    games = ko.VecGames(n, 500)
+    _, mask, _ = games.observe()
+    rng = np.random.default_rng(42)
+    steps = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        acts = np.array([np.nonzero(mask[i])[0][rng.integers(int(mask[i].sum()))] for i in range(n)], np.int64)
+        _, mask, _, _, _, _, _ = games.step(acts, auto_reset=True)
+        steps += n
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d random-legal self-play env steps (16 games from the start position, max_moves 500, "
+                      "auto-reset; step + 46-plane obs + 13527 mask) in %.1f s on one host core of %d; "
+                      "the Python reference itself measured 18-34 env-steps/s/core (BASELINE.md)" %
+                      (steps, dt, os.cpu_count() or 0)}
+
+
+def env_roofline(dev, n_games, replay_steps, seed):
+    """Average device time of ksh_env_step_kernel from `replay_steps` back-to-back launches between two
+    hipEvents on the launch stream: a recorded self-play action stream is replayed on a second env."""
+    from shogidrl_amd import ops
+    from shogidrl_amd.env import DeviceTimer, VecShogiEnv
+    live = VecShogiEnv(n_games, 500, device=dev)
+    live.reset()
+    logits = torch.zeros(n_games, 13527, device=dev)
+    warm = 48                                   # desynchronise the games first (opening plies are the cheap ones)
+    acts = []
+    for t in range(warm + replay_steps):
+        a, _ = ops.masked_sample(logits, live.legal_mask, seed, t)
+        live.step(a, validate=False)
+        acts.append(a)
+    rep = VecShogiEnv(n_games, 500, device=dev)
+    rep.reset()
+    for t in range(warm):
+        rep.step(acts[t], validate=False)
+    tm = DeviceTimer()
+    torch.cuda.synchronize()
+    tm.start()
+    for t in range(warm, warm + replay_steps):
+        rep.step(acts[t], validate=False)
+    tm.stop()
+    ms = tm.elapsed_ms() / replay_steps
+    same = bool(torch.equal(rep.obs, live.obs) and torch.equal(rep.legal_mask, live.legal_mask))
+    del live, rep
+    achieved = n_games * ENV_BYTES_PER_STEP / (ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "env_kernel_hbm_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            t = json.load(open(tfile))
+            if int(t.get("n_games", -1)) == n_games:
+                traffic = t.get("bytes_per_launch")
+        except (ValueError, OSError):
+            traffic = None
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "ksh_env_step_kernel",
+            "avg_launch_us": round(ms * 1e3, 2), "launches": replay_steps,
+            "algorithmic_bytes_per_launch": n_games * ENV_BYTES_PER_STEP, "replay_deterministic": same}
+
+
+def main():
+    args = parse()
+    from shogidrl_amd import parallel
+    rank, local_rank, world = parallel.init_from_env()
+    if world != args.gpus and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    from shogidrl_amd.agent import PPOConfig, VecPPOAgent
+    from shogidrl_amd.buffer import VecExperienceBuffer
+    from shogidrl_amd.env import DeviceTimer, VecShogiEnv
+    from shogidrl_amd.models import ResTowerActorCritic
+    from shogidrl_amd.rollout import SelfPlayRunner
+
+    torch.manual_seed(42)                        # same init on every rank (then kept in sync by the all-reduce)
+    model = ResTowerActorCritic(46, 13527, args.depth, args.width, 0.25)
+    cfg = PPOConfig(ppo_epochs=args.epochs, minibatch_size=args.minibatch, mixed_precision=True, channels_last=True,
+                    seed=42 + rank)
+    agent = VecPPOAgent(model, cfg, dev)
+    env = VecShogiEnv(args.games, 500, device=dev)
+    buf = VecExperienceBuffer(args.rollout, args.games, cfg.gamma, cfg.lambda_gae, dev)
+    runner = SelfPlayRunner(env, agent, buf)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        runner.iteration()
+    t_roll = DeviceTimer()
+    t_upd = DeviceTimer()
+    roll_ms = upd_ms = 0.0
+    metrics = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t_roll.start()
+        runner.collect()
+        t_roll.stop()
+        t_upd.start()
+        metrics = runner.update()
+        t_upd.stop()
+        roll_ms += t_roll.elapsed_ms()
+        upd_ms += t_upd.elapsed_ms()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed, roll_ms, upd_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, roll_ms, upd_ms = (float(x) for x in t.cpu())
+    transitions = world * args.steps * args.rollout * args.games
+    out = None
+    if rank == 0:
+        roof = env_roofline(dev, args.games, args.replay, 42)
+        out = {
+            "metric": "env-steps/sec self-play + PPO samples/sec, 4096 games, 1/2/4/8 MI355X",
+            "value": transitions / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[2]: %d batched self-play games per GPU, ResNet %dx%d+SE0.25 actor-critic "
+                            "(random init), bf16 autocast tower / fp32 heads, rollout T=%d, GAE, PPO %d epochs x "
+                            "minibatch %d, Adam" % (args.games, args.depth, args.width, args.rollout, args.epochs, args.minibatch),
+                "games_per_gpu": args.games, "rollout_len": args.rollout, "ppo_epochs": args.epochs,
+                "minibatch_size": args.minibatch, "parallelism": "dp%d (games sharded, flat-gradient all-reduce)" % world,
+                "env_dtype": "u32 bitboards -> f32 obs / u8 mask",
+            },
+            "selfplay_env_steps_per_s": transitions / (roll_ms * 1e-3),
+            "ppo_samples_per_s": transitions * args.epochs / (upd_ms * 1e-3),
+            "env_kernel_env_steps_per_s": args.games / (roof["avg_launch_us"] * 1e-6),
+            "roofline": roof,
+            "ppo_metrics": metrics,
+            "episodes": runner.episode_stats(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,162 @@
+"""VecPPOAgent -- batched counterpart of keisei/core/ppo_agent.py:PPOAgent for the GPU path.
+
+  select_actions / select_action  <- PPOAgent.select_action (ppo_agent.py:134-223): model.train(is_training),
+                                     no_grad forward, masked categorical sample / arg-max, log-prob, value
+  get_values / get_value          <- PPOAgent.get_value (ppo_agent.py:225-241): eval-mode bootstrap value
+  learn                           <- PPOAgent.learn (ppo_agent.py:243-460): whole-batch advantage normalisation,
+                                     ppo_epochs x shuffled minibatches, clipped surrogate + value + entropy loss,
+                                     grad-norm clipping, Adam, same metric keys
+
+The network forward/backward stays in PyTorch-ROCm; everything after the logits (masked soft-max, sampling,
+log-prob, entropy, the PPO loss and its gradient) runs in the HIP kernels of shogidrl_amd.ops.  Unlike the
+reference there are no per-step `.item()` host syncs: metrics accumulate on the device and are read once
+per learn() call."""
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import ops
+from .mapper import PolicyOutputMapper
+from .parallel import FlatGradBucket, all_reduce_mean_, global_advantage_moments
+
+
+@dataclass
+class PPOConfig:
+    # defaults = default_config.yaml of the reference
+    gamma: float = 0.99
+    lambda_gae: float = 0.95
+    clip_epsilon: float = 0.2
+    value_loss_coeff: float = 0.5
+    entropy_coef: float = 0.01
+    ppo_epochs: int = 10
+    minibatch_size: int = 64
+    learning_rate: float = 3e-4
+    weight_decay: float = 0.0
+    gradient_clip_max_norm: float = 0.5
+    normalize_advantages: bool = True
+    enable_value_clipping: bool = False
+    mixed_precision: bool = False          # bf16 autocast of the tower (the reference uses fp16 + GradScaler)
+    channels_last: bool = False
+    seed: int = 42
+
+
+class VecPPOAgent:
+    def __init__(self, model, config=None, device="cuda:0", group=None, name="PPOAgent"):
+        self.config = config or PPOConfig()
+        self.device = torch.device(device)
+        self.name = name
+        self.model = model.to(self.device)
+        if self.config.channels_last:
+            self.model = self.model.to(memory_format=torch.channels_last)
+        self.group = group
+        self.policy_output_mapper = PolicyOutputMapper()
+        self.num_actions_total = self.policy_output_mapper.get_total_actions()
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        self.bucket = FlatGradBucket(params, group)
+        kw = dict(lr=self.config.learning_rate, weight_decay=self.config.weight_decay)
+        try:
+            self.optimizer = torch.optim.Adam(params, fused=True, **kw)
+        except (RuntimeError, TypeError, ValueError):
+            self.optimizer = torch.optim.Adam(params, **kw)
+        self._rng = np.random.default_rng(self.config.seed)       # minibatch shuffling (ppo_agent.py:100, 298)
+        self._sample_step = 0
+        self.last_kl_div = 0.0
+        self.last_gradient_norm = 0.0
+
+    # ------------------------------------------------------------------ acting
+    def _forward(self, obs):
+        if self.config.channels_last:
+            obs = obs.contiguous(memory_format=torch.channels_last)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=self.config.mixed_precision):
+            logits, value = self.model(obs)
+        return logits, value.float().reshape(-1)
+
+    @torch.no_grad()
+    def select_actions(self, obs, legal_mask, *, is_training=True):
+        """obs [N,46,9,9], legal_mask bool [N,13527] -> (action int64 [N], log_prob [N], value [N])."""
+        self.model.train(is_training)                              # BatchNorm uses batch statistics while acting
+        logits, value = self._forward(obs)
+        action, logp = ops.masked_sample(logits, legal_mask, self.config.seed, self._sample_step,
+                                         deterministic=not is_training)
+        self._sample_step += 1
+        return action, logp, value
+
+    @torch.no_grad()
+    def get_values(self, obs):
+        self.model.eval()
+        _, value = self._forward(obs)
+        return value
+
+    def select_action(self, obs, legal_mask, *, is_training=True):
+        """Single-game signature of the reference: (move tuple | None, index, log_prob, value)."""
+        o = torch.as_tensor(obs, dtype=torch.float32, device=self.device).reshape(1, 46, 9, 9)
+        m = torch.as_tensor(legal_mask, device=self.device).reshape(1, -1).to(torch.bool)
+        a, lp, v = self.select_actions(o, m, is_training=is_training)
+        idx = int(a.item())
+        return self.policy_output_mapper.policy_index_to_shogi_move(idx), idx, float(lp.item()), float(v.item())
+
+    def get_value(self, obs):
+        o = torch.as_tensor(obs, dtype=torch.float32, device=self.device).reshape(1, 46, 9, 9)
+        return float(self.get_values(o).item())
+
+    # ------------------------------------------------------------------ learning
+    def learn(self, buffer):
+        cfg = self.config
+        self.model.train()
+        batch = buffer.get_batch()
+        lr = self.optimizer.param_groups[0]["lr"]
+        if not batch or batch["obs"].shape[0] == 0:
+            return {"ppo/policy_loss": 0.0, "ppo/value_loss": 0.0, "ppo/entropy": 0.0,
+                    "ppo/kl_divergence_approx": self.last_kl_div, "ppo/learning_rate": lr}
+        obs, actions, old_logp = batch["obs"], batch["actions"], batch["log_probs"]
+        old_values, adv, ret, masks = batch["values"], batch["advantages"], batch["returns"], batch["legal_masks"]
+        if cfg.normalize_advantages:
+            n, mean, std = global_advantage_moments(adv, self.group)
+            ok = (std > 1e-8) & (n > 1)                            # ppo_agent.py:277-282, decided on the device
+            adv = torch.where(ok, ((adv.double() - mean) / torch.where(ok, std, torch.ones_like(std))).float(), adv)
+        num = obs.shape[0]
+        indices = np.arange(num)
+        acc = torch.zeros(8, dtype=torch.float32, device=self.device)
+        gnorm = torch.zeros((), dtype=torch.float32, device=self.device)
+        updates = 0
+        for _ in range(cfg.ppo_epochs):
+            self._rng.shuffle(indices)
+            perm = torch.from_numpy(indices).to(self.device, non_blocking=True)
+            for start in range(0, num, cfg.minibatch_size):
+                idx = perm[start:start + cfg.minibatch_size]
+                logits, values = self._forward(obs.index_select(0, idx))
+                loss, stats = ops.ppo_loss(logits, values, masks.index_select(0, idx), actions.index_select(0, idx),
+                                           old_logp.index_select(0, idx), adv.index_select(0, idx),
+                                           ret.index_select(0, idx), old_values.index_select(0, idx),
+                                           cfg.clip_epsilon, cfg.value_loss_coeff, cfg.entropy_coef,
+                                           cfg.enable_value_clipping)
+                self.bucket.zero()
+                loss.backward()
+                self.bucket.all_reduce_mean()                      # RCCL over xGMI when world_size > 1
+                flat = self.bucket.flat
+                gnorm = torch.linalg.vector_norm(flat)
+                flat.mul_(torch.clamp(cfg.gradient_clip_max_norm / (gnorm + 1e-6), max=1.0))  # clip_grad_norm_
+                self.optimizer.step()
+                acc += stats
+                updates += 1
+        acc = all_reduce_mean_(acc / max(updates, 1), self.group).cpu()   # the single host sync of learn()
+        self.last_gradient_norm = float(gnorm)
+        self.last_kl_div = float(acc[4])
+        return {"ppo/policy_loss": float(acc[1]), "ppo/value_loss": float(acc[2]), "ppo/entropy": float(acc[3]),
+                "ppo/kl_divergence_approx": float(acc[4]), "ppo/clip_fraction": float(acc[5]),
+                "ppo/learning_rate": self.optimizer.param_groups[0]["lr"]}
+
+    # ------------------------------------------------------------------ checkpoints (ppo_agent.py:462-537 dict layout)
+    def save_model(self, file_path, global_timestep=0, total_episodes_completed=0, stats_to_save=None):
+        d = {"model_state_dict": self.model.state_dict(), "optimizer_state_dict": self.optimizer.state_dict(),
+             "global_timestep": global_timestep, "total_episodes_completed": total_episodes_completed}
+        d.update(stats_to_save or {})
+        torch.save(d, file_path)
+
+    def load_model(self, file_path):
+        ck = torch.load(file_path, map_location=self.device, weights_only=True)
+        self.model.load_state_dict(ck["model_state_dict"])
+        if "optimizer_state_dict" in ck:
+            self.optimizer.load_state_dict(ck["optimizer_state_dict"])
+        return ck

@@ -1,0 +1,121 @@
+"""Experience storage for the PPO path.
+
+ExperienceBuffer      -- the reference's single-stream buffer, same constructor / methods / error behaviour
+                         (keisei/core/experience_buffer.py:26-209), GAE by the HIP scan kernel (N = 1).
+VecExperienceBuffer   -- the batched [T, N] counterpart the GPU rollout fills in place: the env kernel writes
+                         the next observation / mask straight into slot t+1, nothing is copied per step.
+"""
+import warnings
+
+import torch
+
+from . import ops
+from ._lib import NUM_ACTIONS
+
+
+class ExperienceBuffer:
+    def __init__(self, buffer_size, gamma, lambda_gae, device="cuda:0"):
+        self.buffer_size, self.gamma, self.lambda_gae = buffer_size, gamma, lambda_gae
+        self.device = torch.device(device)
+        d = self.device
+        self.obs = torch.zeros((buffer_size, 46, 9, 9), dtype=torch.float32, device=d)
+        self.actions = torch.zeros(buffer_size, dtype=torch.int64, device=d)
+        self.rewards = torch.zeros(buffer_size, dtype=torch.float32, device=d)
+        self.log_probs = torch.zeros(buffer_size, dtype=torch.float32, device=d)
+        self.values = torch.zeros(buffer_size, dtype=torch.float32, device=d)
+        self.dones = torch.zeros(buffer_size, dtype=torch.bool, device=d)
+        self.legal_masks = torch.zeros((buffer_size, NUM_ACTIONS), dtype=torch.bool, device=d)
+        self.advantages = torch.zeros(buffer_size, dtype=torch.float32, device=d)
+        self.returns = torch.zeros(buffer_size, dtype=torch.float32, device=d)
+        self.ptr = 0
+        self._advantages_computed = False
+
+    def add(self, obs, action, reward, log_prob, value, done, legal_mask):
+        if self.ptr >= self.buffer_size:
+            warnings.warn("ExperienceBuffer: Buffer is full. Cannot add new experience.")
+            return
+        i = self.ptr
+        self.obs[i] = torch.as_tensor(obs).to(self.device)
+        self.actions[i] = action
+        self.rewards[i] = reward
+        self.log_probs[i] = log_prob
+        self.values[i] = value
+        self.dones[i] = done
+        self.legal_masks[i] = torch.as_tensor(legal_mask).to(self.device)
+        self.ptr += 1
+
+    def compute_advantages_and_returns(self, last_value):
+        if self.ptr == 0:
+            warnings.warn("ExperienceBuffer: compute_advantages_and_returns called on an empty buffer.")
+            return
+        n = self.ptr
+        lv = torch.tensor([float(last_value)], dtype=torch.float32, device=self.device)
+        adv, ret = ops.gae(self.rewards[:n, None], self.values[:n, None], self.dones[:n, None], lv, self.gamma,
+                           self.lambda_gae)
+        self.advantages[:n] = adv[:, 0]
+        self.returns[:n] = ret[:, 0]
+        self._advantages_computed = True
+
+    def get_batch(self):
+        if self.ptr == 0:
+            warnings.warn("ExperienceBuffer: get_batch called on an empty or not-yet-computed buffer.")
+            return {}
+        if not self._advantages_computed:
+            raise RuntimeError("Cannot get batch: compute_advantages_and_returns() must be called first")
+        n = self.ptr
+        return {"obs": self.obs[:n], "actions": self.actions[:n], "log_probs": self.log_probs[:n],
+                "values": self.values[:n], "rewards": self.rewards[:n], "advantages": self.advantages[:n],
+                "returns": self.returns[:n], "dones": self.dones[:n], "legal_masks": self.legal_masks[:n]}
+
+    def clear(self):
+        self.ptr = 0
+        self._advantages_computed = False
+
+    def __len__(self):
+        return self.ptr
+
+    def size(self):
+        return self.ptr
+
+    def capacity(self):
+        return self.buffer_size
+
+
+class VecExperienceBuffer:
+    """[T, N] rollout storage; obs / legal_masks have T+1 slots (slot T holds the bootstrap observation)."""
+
+    def __init__(self, horizon, num_games, gamma, lambda_gae, device="cuda:0"):
+        self.T, self.N, self.gamma, self.lambda_gae = horizon, num_games, gamma, lambda_gae
+        self.device = torch.device(device)
+        d, T, N = self.device, horizon, num_games
+        self.obs = torch.empty((T + 1, N, 46, 9, 9), dtype=torch.float32, device=d)
+        self.legal_masks = torch.empty((T + 1, N, NUM_ACTIONS), dtype=torch.bool, device=d)
+        self.actions = torch.zeros((T, N), dtype=torch.int64, device=d)
+        self.rewards = torch.zeros((T, N), dtype=torch.float32, device=d)
+        self.log_probs = torch.zeros((T, N), dtype=torch.float32, device=d)
+        self.values = torch.zeros((T, N), dtype=torch.float32, device=d)
+        self.dones = torch.zeros((T, N), dtype=torch.bool, device=d)
+        self.advantages = torch.zeros((T, N), dtype=torch.float32, device=d)
+        self.returns = torch.zeros((T, N), dtype=torch.float32, device=d)
+        self._advantages_computed = False
+
+    def compute_advantages_and_returns(self, last_values):
+        """last_values: float32 [N] bootstrap values of obs[T] (experience_buffer.py:99-145 per game)."""
+        self.advantages, self.returns = ops.gae(self.rewards, self.values, self.dones, last_values, self.gamma,
+                                                self.lambda_gae)
+        self._advantages_computed = True
+
+    def get_batch(self):
+        if not self._advantages_computed:
+            raise RuntimeError("Cannot get batch: compute_advantages_and_returns() must be called first")
+        T, N = self.T, self.N
+        f = lambda x: x.reshape(T * N, *x.shape[2:])
+        return {"obs": f(self.obs[:T]), "actions": f(self.actions), "log_probs": f(self.log_probs),
+                "values": f(self.values), "rewards": f(self.rewards), "advantages": f(self.advantages),
+                "returns": f(self.returns), "dones": f(self.dones), "legal_masks": f(self.legal_masks[:T])}
+
+    def clear(self):
+        # carry the bootstrap observation over as the first observation of the next rollout
+        self.obs[0].copy_(self.obs[self.T])
+        self.legal_masks[0].copy_(self.legal_masks[self.T])
+        self._advantages_computed = False

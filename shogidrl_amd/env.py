@@ -21,6 +21,22 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class _Lazy:
+    """terminated / truncated flags computed only if somebody looks at them (keeps the hot loop at one launch)."""
+
+    def __init__(self, env, name):
+        self._env, self._name = env, name
+
+    def tensor(self):
+        return getattr(self._env, self._name)
+
+    def __getattr__(self, k):
+        return getattr(self.tensor(), k)
+
+    def __bool__(self):
+        return bool(self.tensor())
+
+
 class VecShogiEnv:
     def __init__(self, num_games, max_moves_per_game=500, device="cuda:0", auto_reset=True):
         self.device = torch.device(device)
@@ -62,11 +78,15 @@ class VecShogiEnv:
         return self
 
     # ------------------------------------------------------------------ API
-    def reset(self, reset_mask=None):
+    def reset(self, reset_mask=None, out_obs=None, out_mask=None):
         """Reset all games (or those where reset_mask is True). Returns (obs, legal_mask)."""
         rm = None
         if reset_mask is not None:
             rm = reset_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        if out_obs is not None:
+            self.obs = out_obs
+        if out_mask is not None:
+            self.legal_mask = out_mask
         check(self._L.ksh_env_reset(self._h, rm.data_ptr() if rm is not None else None, self.obs.data_ptr(),
                                     self.legal_mask.data_ptr(), self.n_legal.data_ptr(), _stream()), "ksh_env_reset")
         return self.obs, self.legal_mask
@@ -76,26 +96,38 @@ class VecShogiEnv:
                                       _stream()), "ksh_env_observe")
         return self.obs, self.legal_mask
 
-    def step(self, actions, validate=True, out_obs=None, out_mask=None):
-        """actions: int64 [N] on the device. Returns (obs, reward, terminated, truncated, info)."""
+    def step(self, actions, validate=True, out_obs=None, out_mask=None, prev_mask=None):
+        """actions: int64 [N] on the device.  Returns (obs, reward, terminated, truncated, info).
+
+        out_obs / out_mask: where the kernel writes the next observation / mask (default: the env's own
+        buffers); prev_mask: the mask the actions were drawn from (default: the mask of the previous call),
+        used to reject illegal actions when validate is True."""
         if actions.dtype != torch.int64 or actions.device != self.device or actions.numel() != self.num_games:
             raise ValueError("actions must be an int64 tensor of shape [%d] on %s" % (self.num_games, self.device))
         actions = actions.contiguous()
         obs = self.obs if out_obs is None else out_obs
         mask = self.legal_mask if out_mask is None else out_mask
-        prev = self.legal_mask.data_ptr() if validate else None
+        if not obs.is_contiguous() or not mask.is_contiguous():
+            raise ValueError("out_obs / out_mask must be contiguous")
+        prev = None
+        if validate:
+            prev = (self.legal_mask if prev_mask is None else prev_mask).data_ptr()
         check(self._L.ksh_env_step(self._h, actions.data_ptr(), prev, obs.data_ptr(), mask.data_ptr(),
                                    self.n_legal.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(),
                                    self.reason.data_ptr(), self.winner.data_ptr(), int(self.auto_reset), _stream()),
               "ksh_env_step")
-        if out_mask is not None:
-            self.legal_mask = out_mask
-        if out_obs is not None:
-            self.obs = out_obs
-        truncated = self.reason == 3
-        terminated = self.done & ~truncated
-        info = {"reason": self.reason, "winner": self.winner, "n_legal": self.n_legal, "done": self.done}
-        return obs, self.reward, terminated, truncated, info
+        self.obs, self.legal_mask = obs, mask
+        return obs, self.reward, _Lazy(self, "terminated"), _Lazy(self, "truncated"), \
+            {"reason": self.reason, "winner": self.winner, "n_legal": self.n_legal, "done": self.done}
+
+    @property
+    def truncated(self):
+        """"Max moves reached" (the reference's buffer treats it as done as well, step_manager.py:273-281)."""
+        return self.reason == 3
+
+    @property
+    def terminated(self):
+        return self.done & (self.reason != 3)
 
     # ------------------------------------------------------------------ host-side state exchange (tests / fixtures)
     def set_state(self, game, rec128):

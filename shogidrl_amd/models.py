@@ -1,0 +1,91 @@
+"""Actor-critic networks of the hot path's callers, kept in PyTorch-ROCm (north_star: the ResNet/SE tower
+stays in PyTorch so EnvManager/PPOAgent/Trainer stay drop-in).  Parameter names match the reference's
+state dicts (keisei/core/neural_network.py:10-29, keisei/training/models/resnet_tower.py:15-83) so its
+checkpoints load: stem, bn_stem, res_blocks.{i}.{conv1,bn1,conv2,bn2,se.fc1,se.fc2}, policy_head.{0,1,4},
+value_head.{0,1,4}.  forward(obs) -> (policy_logits [B,13527], value [B]); the masked soft-max / sampling /
+loss tail is NOT here -- it runs in the HIP kernels (shogidrl_amd.ops)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ._lib import NUM_ACTIONS
+
+
+class TinyActorCritic(nn.Module):
+    """conv3x3(46->16) + two Linear heads on 16*81 features (reference ActorCritic)."""
+
+    def __init__(self, input_channels=46, num_actions_total=NUM_ACTIONS):
+        super().__init__()
+        self.conv = nn.Conv2d(input_channels, 16, kernel_size=3, padding=1)
+        self.policy_head = nn.Linear(16 * 81, num_actions_total)
+        self.value_head = nn.Linear(16 * 81, 1)
+
+    def forward(self, x):
+        h = torch.flatten(F.relu(self.conv(x)), 1)
+        return self.policy_head(h), self.value_head(h).squeeze(-1)
+
+
+class _SE(nn.Module):
+    def __init__(self, channels, ratio):
+        super().__init__()
+        hidden = max(1, int(channels * ratio))
+        self.fc1 = nn.Conv2d(channels, hidden, 1)
+        self.fc2 = nn.Conv2d(hidden, channels, 1)
+
+    def forward(self, x):
+        s = x.mean(dim=(2, 3), keepdim=True)
+        return x * torch.sigmoid(self.fc2(F.relu(self.fc1(s))))
+
+
+class _Block(nn.Module):
+    def __init__(self, channels, se_ratio):
+        super().__init__()
+        self.conv1 = nn.Conv2d(channels, channels, 3, padding=1)
+        self.bn1 = nn.BatchNorm2d(channels)
+        self.conv2 = nn.Conv2d(channels, channels, 3, padding=1)
+        self.bn2 = nn.BatchNorm2d(channels)
+        self.se = _SE(channels, se_ratio) if se_ratio else None
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        if self.se is not None:
+            y = self.se(y)
+        return F.relu(y + x)
+
+
+class ResTowerActorCritic(nn.Module):
+    """ResNet tower + optional squeeze-excitation, slim 2-plane policy / value heads (reference
+    ActorCriticResTower; default 9 blocks x 256 channels, SE 0.25 = 13 241 300 parameters)."""
+
+    def __init__(self, input_channels=46, num_actions_total=NUM_ACTIONS, tower_depth=9, tower_width=256, se_ratio=0.25):
+        super().__init__()
+        self.stem = nn.Conv2d(input_channels, tower_width, 3, padding=1)
+        self.bn_stem = nn.BatchNorm2d(tower_width)
+        self.res_blocks = nn.Sequential(*[_Block(tower_width, se_ratio) for _ in range(tower_depth)])
+        self.policy_head = nn.Sequential(nn.Conv2d(tower_width, 2, 1), nn.BatchNorm2d(2), nn.ReLU(), nn.Flatten(),
+                                         nn.Linear(2 * 81, num_actions_total))
+        self.value_head = nn.Sequential(nn.Conv2d(tower_width, 2, 1), nn.BatchNorm2d(2), nn.ReLU(), nn.Flatten(),
+                                        nn.Linear(2 * 81, 1))
+
+    def trunk(self, x):
+        return self.res_blocks(F.relu(self.bn_stem(self.stem(x))))
+
+    def forward(self, x):
+        h = self.trunk(x)
+        # heads in float32 even under bf16 autocast: the logits feed the soft-max / PPO-loss kernels
+        with torch.autocast(device_type=x.device.type, enabled=False):
+            h32 = h.float()
+            return self.policy_head(h32), self.value_head(h32).squeeze(-1)
+
+
+def model_factory(model_type, obs_shape=(46, 9, 9), num_actions=NUM_ACTIONS, tower_depth=9, tower_width=256,
+                  se_ratio=0.25, **_unused):
+    """Same dispatch keys as keisei/training/models/__init__.py:6 (plus the tiny CNN)."""
+    if model_type in ("resnet", "dummy", "testmodel", "resumemodel"):
+        if model_type != "resnet":
+            tower_depth, tower_width, se_ratio = 1, 16, None
+        return ResTowerActorCritic(obs_shape[0], num_actions, tower_depth, tower_width, se_ratio)
+    if model_type in ("tiny", "cnn"):
+        return TinyActorCritic(obs_shape[0], num_actions)
+    raise ValueError("Unknown model_type: %s" % model_type)
