@@ -26,7 +26,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -134,7 +133,7 @@ def main():
 
     torch.manual_seed(42)                        # same init on every rank (then kept in sync by the all-reduce)
     model = ResTowerActorCritic(46, 13527, args.depth, args.width, 0.25)
-    cfg = PPOConfig(ppo_epochs=args.epochs, minibatch_size=args.minibatch, mixed_precision=True, channels_last=True,
+    cfg = PPOConfig(ppo_epochs=args.epochs, minibatch_size=args.minibatch, mixed_precision=True, channels_last=False,
                     seed=42 + rank)
     agent = VecPPOAgent(model, cfg, dev)
     env = VecShogiEnv(args.games, 500, device=dev)
@@ -147,8 +146,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        runner.iteration()
+    def note(msg):
+        if rank == 0:
+            print("[bench %7.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
+    t_start = time.perf_counter()
+    for i in range(args.warmup):
+        runner.collect()
+        torch.cuda.synchronize()
+        note("warmup %d: rollout done" % i)
+        runner.update()
+        note("warmup %d: update done" % i)
     t_roll = DeviceTimer()
     t_upd = DeviceTimer()
     roll_ms = upd_ms = 0.0
@@ -164,6 +172,7 @@ def main():
         t_upd.stop()
         roll_ms += t_roll.elapsed_ms()
         upd_ms += t_upd.elapsed_ms()
+        note("timed step done (rollout %.2f s, update %.2f s so far)" % (roll_ms * 1e-3, upd_ms * 1e-3))
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -42,7 +42,8 @@ class FlatGradBucket:
         self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            # same sizes AND strides as the parameter (channels_last weights keep their layout)
+            p.grad = self.flat[off:off + p.numel()].as_strided(p.size(), p.stride())
             off += p.numel()
 
     def zero(self):
