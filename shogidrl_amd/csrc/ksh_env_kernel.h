@@ -57,7 +57,20 @@ struct KshStepArgs {
     int hist_cap;
     int mode;                  // 0 observe, 1 reset (masked), 2 step
     int auto_reset;
+    unsigned long long *stamps; // diagnostic build only (-DKSH_STAMPS): [N][16] s_memtime values
 };
+
+// Diagnostic build: per-phase shader-clock stamps of lane 0 of every wave (never compiled into the product .so).
+#ifdef KSH_STAMPS
+#define KSH_STAMP(k)                                                                         \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        if (lane == 0 && a.stamps) a.stamps[(size_t)g * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+    } while (0)
+#else
+#define KSH_STAMP(k) do { } while (0)
+#endif
 
 struct BB3 {
     uint32_t w0, w1, w2;
@@ -439,6 +452,9 @@ __device__ __forceinline__ float ksh_obs_value(const KshWaveLds &W, int f, float
 
 extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(KshStepArgs a) {
     __shared__ KshBlockLds L;
+#ifdef KSH_STAMPS
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
     // stage the attack tables in LDS (24.8 KB, shared by the block's waves)
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.tables);
@@ -452,12 +468,17 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
     if (g >= a.n_games) return;  // wave-uniform
     KshWaveLds &W = L.wave[wv];
     uint8_t *st8 = ST8(W);
+#ifdef KSH_STAMPS
+    if (lane == 0 && a.stamps) a.stamps[(size_t)g * 16 + 0] = t_entry;
+#endif
+    KSH_STAMP(1);  // tables staged
 
     // ---- load the state record, clear the legal bit-set
     if (lane < 32) W.st32[lane] = reinterpret_cast<const uint32_t *>(a.state + (size_t)g * 128)[lane];
     for (int i = lane; i < KSH_MASKW; i += 64) W.maskbits[i] = 0;
     wave_lds_sync();
 
+    KSH_STAMP(2);  // state loaded
     int out_done = 0, out_reason = 0, out_winner = -1, n_out = 0;
     float out_reward = 0.0f;
     bool need_gen = true;
@@ -545,8 +566,10 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
                 me = 1 - mover;
                 const int mc = st8[S_MC] | (st8[S_MC + 1] << 8);
                 const int hbase = st8[S_HBASE] | (st8[S_HBASE + 1] << 8);
+                KSH_STAMP(3);  // move applied
                 // ---- position key of the post-move state, appended to the game's history
                 const unsigned long long h = ksh_hash(W, lane);
+                KSH_STAMP(4);  // hashed
                 const int idx = mc - 1 - hbase;
                 unsigned long long *hrow = a.hist + (size_t)g * (size_t)a.hist_cap;
                 int rep = 1;
@@ -560,9 +583,11 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
                     }
                     rep += matches;
                 }
+                KSH_STAMP(5);  // history scanned
                 // ---- legal moves of the side now to move (+ nested uchi-fu-zume reply search)
                 bool chk;
                 int n = ksh_gen_full(L, W, lane, me, chk);
+                KSH_STAMP(6);  // movegen done
                 need_gen = false;
                 n_out = n;
                 // ---- termination (shogi_game.py:408-450): no moves -> max moves -> sennichite
@@ -601,6 +626,7 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
         n_out = n;
     }
     wave_lds_sync();
+    KSH_STAMP(7);  // termination / reset-regen done
     if (lane == 0) a.n_legal[g] = n_out;
 
     // ---- write back the state and the per-game scalars
@@ -634,6 +660,7 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
         W.handv[lane] = (float)((double)cnt / 18.0);
     }
     wave_lds_sync();
+    KSH_STAMP(8);  // obs tables built
     const float black_flag = side == 0 ? 1.0f : 0.0f;
     const int mcount = st8[S_MC] | (st8[S_MC + 1] << 8);
     const float move_frac = a.max_moves > 0 ? (float)((double)mcount / (double)a.max_moves) : 0.0f;
@@ -660,6 +687,7 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
         }
     }
 
+    KSH_STAMP(9);  // obs stores issued
     // ---- legal mask: expand the bit-set to one byte per action, 16-byte aligned stores
     {
         uint8_t *mrow = a.mask + (size_t)g * KSH_A;
@@ -685,4 +713,5 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
             mrow[b] = (uint8_t)((W.maskbits[b >> 5] >> (b & 31)) & 1u);
         }
     }
+    KSH_STAMP(10);  // mask stores issued
 }

@@ -91,6 +91,8 @@ int ksh_env_destroy(void *handle) {
 int ksh_env_num_games(void *handle) { return handle ? ((KshEnv *)handle)->n : KSH_E_ARG; }
 int ksh_env_max_moves(void *handle) { return handle ? ((KshEnv *)handle)->max_moves : KSH_E_ARG; }
 
+static unsigned long long *g_stamps = nullptr;  // diagnostic builds only (ksh_debug_set_stamps)
+
 static int launch_env(KshEnv *e, int mode, const int64_t *actions, const uint8_t *prev_mask, const uint8_t *reset_mask,
                       float *obs, uint8_t *mask, int32_t *n_legal, float *reward, uint8_t *done, uint8_t *reason,
                       int8_t *winner, int auto_reset, void *stream) {
@@ -116,6 +118,7 @@ static int launch_env(KshEnv *e, int mode, const int64_t *actions, const uint8_t
     a.hist_cap = e->hist_cap;
     a.mode = mode;
     a.auto_reset = auto_reset;
+    a.stamps = g_stamps;
     const int blocks = (e->n + KSH_WPB - 1) / KSH_WPB;
     hipLaunchKernelGGL(ksh_env_step_kernel, dim3(blocks), dim3(64 * KSH_WPB), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
@@ -239,6 +242,10 @@ int ksh_ppo_loss_fwd_bwd(const void *logits, int logits_dtype, const uint8_t *ma
     HIP_TRY(hipGetLastError());
     return KSH_OK;
 }
+
+#ifdef KSH_STAMPS
+int ksh_debug_set_stamps(void *dev_buffer) { g_stamps = (unsigned long long *)dev_buffer; return KSH_OK; }
+#endif
 
 // ---------------------------------------------------------------------------------- timing helpers
 int ksh_event_create(void **ev) {

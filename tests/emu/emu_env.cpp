@@ -18,7 +18,7 @@ void emu_env_launch(uint8_t *state, unsigned long long *hist, const void *tables
     a.state = state; a.hist = hist; a.tables = (const KshTables *)tables; a.actions = actions;
     a.prev_mask = prev_mask; a.reset_mask = reset_mask; a.obs = obs; a.mask = mask; a.n_legal = n_legal;
     a.reward = reward; a.done = done; a.reason = reason; a.winner = winner; a.n_games = n_games;
-    a.max_moves = max_moves; a.hist_cap = hist_cap; a.mode = mode; a.auto_reset = auto_reset;
+    a.max_moves = max_moves; a.hist_cap = hist_cap; a.mode = mode; a.auto_reset = auto_reset; a.stamps = nullptr;
     g_args = a;
     const int nblocks = (n_games + KSH_WPB - 1) / KSH_WPB;
     for (int b = 0; b < nblocks; b++) emu::run_block(entry, nullptr, b, 64 * KSH_WPB);
