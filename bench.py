@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--replay", type=int, default=96, help="env launches in the roofline replay")
+    ap.add_argument("--roofline-only", action="store_true", help="only time the env kernel (quick check)")
     return ap.parse_args()
 
 
@@ -125,6 +126,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
+    if args.roofline_only:
+        print(json.dumps(env_roofline(dev, args.games, args.replay, 42)))
+        return
     from shogidrl_amd.agent import PPOConfig, VecPPOAgent
     from shogidrl_amd.buffer import VecExperienceBuffer
     from shogidrl_amd.env import DeviceTimer, VecShogiEnv

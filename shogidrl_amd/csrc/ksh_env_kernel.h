@@ -42,6 +42,7 @@ struct KshStepArgs {
     uint8_t *state;            // [N][128]
     unsigned long long *hist;  // [N][hist_cap] position hashes of post-move states
     const KshTables *tables;
+    const float *move_lut;     // [hist_cap]: (float)((double)i / (double)max_moves), the move-count plane value
     const long long *actions;  // [N] or null (mode != 2)
     const uint8_t *prev_mask;  // [N][A] or null
     const uint8_t *reset_mask; // [N] or null (mode 1)
@@ -65,7 +66,7 @@ struct KshStepArgs {
 #define KSH_STAMP(k)                                                                         \
     do {                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                   \
-        if (lane == 0 && a.stamps) a.stamps[(size_t)g * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+        if (lane == 0 && a.stamps) a.stamps[(size_t)g * 32 + (k)] = __builtin_amdgcn_s_memtime(); \
         __builtin_amdgcn_sched_barrier(0);                                                   \
     } while (0)
 #else
@@ -152,15 +153,37 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Wave-wide reductions by xor-butterfly (ds_bpermute): every lane ends up with the result.  (LDS atomics
+// on one address are turned by hipcc into a serial readlane loop over the active lanes -- far slower.)
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v |= (uint32_t)__shfl_xor((int)v, o);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_xor(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v ^= (uint32_t)__shfl_xor((int)v, o);
+    return v;
+}
+// sum of small per-lane counts (< 64) from six ballots, no LDS round trip
+__device__ __forceinline__ int wave_sum_small(int v) {
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) s += __popcll(__ballot((v >> k) & 1)) << k;
+    return s;
+}
+
 // per-wave LDS scratch
 struct KshWaveLds {
     uint32_t maskbits[KSH_MASKW];  // legal action bit-set, bit i <-> action id i
     uint32_t st32[32];             // the 128-byte state record
     uint8_t plist[64];             // squares of the pieces on the board (compacted)
     uint8_t pin_dir[96];           // per square: ray direction (from the king) it is pinned along, 0xFF none
-    uint8_t plane_of[96];          // per POV square: observation plane of the piece standing there, 0xFF none
-    float handv[16];               // hand planes: own P..R, opponent P..R
-    uint32_t red[8];               // 0-2 enemy attack map, 3 nifu files, 4 count, 5-6 hash
+    uint32_t obsbits[80];          // planes 0-27 of the observation as a bit-set: bit plane*81 + pov_sq (2268 bits)
+    float metav[20];               // planes 28-45: hands (own P..R, opp P..R), side-to-move flag, move fraction, 0, 0
+    float move_frac;               // move-count plane value prefetched for move count move_idx
+    int move_idx;
+    uint32_t pad_[6];
 };
 
 struct KshBlockLds {
@@ -184,8 +207,18 @@ __device__ __forceinline__ BB3 lds_bb(const uint32_t (*tbl)[81][4], int k, int s
 // move is already in check (hand-made positions only) the reference's test "the king is attacked
 // after the drop" (shogi_rules_logic.py:329-332) holds for every pawn drop, so all of them are.
 // ------------------------------------------------------------------------------------------------
+#ifdef KSH_STAMPS
+#define GEN_STAMP(k)                                                              \
+    do {                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+        if (lane == 0 && dbg) dbg[k] = __builtin_amdgcn_s_memtime();              \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+    } while (0)
+#else
+#define GEN_STAMP(k) do { } while (0)
+#endif
 __device__ __forceinline__ int ksh_gen(KshBlockLds &L, KshWaveLds &W, int lane, int me, bool emit, bool want_ufz,
-                                       bool &in_check, BB3 &ufz_cand) {
+                                       bool &in_check, BB3 &ufz_cand, unsigned long long *dbg = nullptr) {
     const uint8_t *brd = ST8(W);
     const int p0 = brd[lane];
     const int p1 = (lane < 17) ? brd[64 + lane] : 0;
@@ -208,9 +241,9 @@ __device__ __forceinline__ int ksh_gen(KshBlockLds &L, KshWaveLds &W, int lane, 
     if (p1 != 0) W.plist[n_lo + __popcll(occ_hi & ((1ull << lane) - 1ull))] = (uint8_t)(64 + lane);
     W.pin_dir[lane] = 0xFF;
     if (lane < 32) W.pin_dir[64 + lane] = 0xFF;
-    if (lane < 5) W.red[lane] = 0;
     wave_lds_sync();
 
+    GEN_STAMP(11);  // occupancy ballots + compaction
     // ---- lane = piece: attack set of every piece on the board
     int sq = 0, pc = 0;
     if (lane < np) { sq = W.plist[lane]; pc = brd[sq]; }
@@ -239,13 +272,10 @@ __device__ __forceinline__ int ksh_gen(KshBlockLds &L, KshWaveLds &W, int lane, 
             att = bb_or(att, ray_attack(M, bb_and(M, O), (d & 1) != 0));
         }
     }
+    GEN_STAMP(12);  // attack sets
     // enemy attack map (OR over enemy pieces) and files holding an own unpromoted pawn (nifu)
-    if (foe) {
-        if (att.w0) atomicOr(&W.red[0], att.w0);
-        if (att.w1) atomicOr(&W.red[1], att.w1);
-        if (att.w2) atomicOr(&W.red[2], att.w2);
-    }
-    if (mine && type == 0) atomicOr(&W.red[3], 1u << (sq - 9 * sq_row(sq)));
+    const BB3 eatt = BB3{wave_or(foe ? att.w0 : 0u), wave_or(foe ? att.w1 : 0u), wave_or(foe ? att.w2 : 0u)};
+    const uint32_t nifu = wave_or((mine && type == 0) ? (1u << (sq - 9 * sq_row(sq))) : 0u);
     // checkers: enemy pieces attacking the king square
     const unsigned long long chk = __ballot(foe && ksq >= 0 && bb_test(att, ksq));
     const int ncheck = __popcll(chk);
@@ -253,6 +283,7 @@ __device__ __forceinline__ int ksh_gen(KshBlockLds &L, KshWaveLds &W, int lane, 
     in_check = (ksq < 0) || ncheck > 0;  // king missing => "in check" (shogi_rules_logic.py:42-55)
     const bool opp_in_check = __ballot(mine && eksq >= 0 && bb_test(att, eksq)) != 0ull;
 
+    GEN_STAMP(13);  // reductions + checkers
     // ---- lane = ray from the king: pins
     if (lane < 8 && ksq >= 0) {
         const int d = lane;
@@ -277,8 +308,6 @@ __device__ __forceinline__ int ksh_gen(KshBlockLds &L, KshWaveLds &W, int lane, 
         }
     }
     wave_lds_sync();
-    const BB3 eatt = BB3{W.red[0], W.red[1], W.red[2]};
-    const uint32_t nifu = W.red[3];
 
     // squares a non-king move must land on while in check; squares a drop may use
     BB3 block = BB3{KSH_M27, KSH_M27, KSH_M27};
@@ -295,6 +324,7 @@ __device__ __forceinline__ int ksh_gen(KshBlockLds &L, KshWaveLds &W, int lane, 
     }
     if (ksq < 0) dropok = bb_zero();
 
+    GEN_STAMP(14);  // pins + block sets
     // ---- lane = own piece: filter to legal targets, emit action ids
     int cnt = 0;
     if (mine && ksq >= 0) {
@@ -338,6 +368,7 @@ __device__ __forceinline__ int ksh_gen(KshBlockLds &L, KshWaveLds &W, int lane, 
         }
     }
 
+    GEN_STAMP(15);  // board moves emitted
     // ---- lane = square: drops (shogi_rules_logic.py:424-483, 562-583)
     const uint8_t *hand = brd + S_HAND + 7 * me;
     uint32_t ht = 0;
@@ -375,9 +406,8 @@ __device__ __forceinline__ int ksh_gen(KshBlockLds &L, KshWaveLds &W, int lane, 
             }
         }
     }
-    if (cnt) atomicAdd(&W.red[4], (uint32_t)cnt);
-    wave_lds_sync();
-    const int total = (int)W.red[4];
+    // a lane emits at most ~40 board targets x2 + 2x7 drop bits; keep the ballot sum exact for any count
+    const int total = wave_sum_small(cnt & 63) + (wave_sum_small(cnt >> 6) << 6);
     wave_lds_sync();
     return total;
 }
@@ -386,10 +416,14 @@ __device__ __forceinline__ int ksh_gen(KshBlockLds &L, KshWaveLds &W, int lane, 
 // Legal moves of `me` including the uchi-fu-zume decision (shogi_rules_logic.py:275-359): for every
 // candidate square drop the pawn on the LDS board, generate the opponent's replies (nested pawn drops
 // skip their own test, :461-467) and keep the drop unless it gives check AND leaves no reply.
-__device__ __forceinline__ int ksh_gen_full(KshBlockLds &L, KshWaveLds &W, int lane, int me, bool &in_check) {
+__device__ __forceinline__ int ksh_gen_full(KshBlockLds &L, KshWaveLds &W, int lane, int me, bool &in_check,
+                                            unsigned long long *dbg = nullptr) {
     uint8_t *st8 = ST8(W);
     BB3 cand;
-    int n = ksh_gen(L, W, lane, me, true, true, in_check, cand);
+    int n = ksh_gen(L, W, lane, me, true, true, in_check, cand, dbg);
+#ifdef KSH_STAMPS
+    if (lane == 0 && dbg) { dbg[10] = __builtin_amdgcn_s_memtime(); dbg[9] = bb_any(cand) ? 1 : 0; }
+#endif
     for (int it = 0; it < 81 && bb_any(cand); it++) {  // wave-uniform; one iteration in reachable positions
         const int s = bb_nearest(cand, true);
         cand = bb_andn(cand, bb_sq(s));
@@ -414,8 +448,6 @@ __device__ __forceinline__ int ksh_gen_full(KshBlockLds &L, KshWaveLds &W, int l
 // (shogi/shogi_game.py:347-372); a 2x32-bit mixed XOR key stands in for it (collision odds ~2^-64 per pair).
 __device__ __forceinline__ unsigned long long ksh_hash(KshWaveLds &W, int lane) {
     const uint8_t *brd = ST8(W);
-    if (lane < 2) W.red[5 + lane] = 0;
-    wave_lds_sync();
     uint32_t ha = 0, hb = 0;
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
@@ -431,23 +463,94 @@ __device__ __forceinline__ unsigned long long ksh_hash(KshWaveLds &W, int lane) 
         ha ^= fmix32(key * 0x9E3779B1u + 0x7F4A7C15u);
         hb ^= fmix32((key ^ 0x5bd1e995u) * 0x2545F491u + 0x1B873593u);
     }
-    if (ha) atomicXor(&W.red[5], ha);
-    if (hb) atomicXor(&W.red[6], hb);
-    wave_lds_sync();
-    unsigned long long h = ((unsigned long long)W.red[6] << 32) | W.red[5];
+    unsigned long long h = ((unsigned long long)wave_xor(hb) << 32) | wave_xor(ha);
     if (brd[S_SIDE]) h ^= 0xA5A5F00D5EED1234ull;
-    wave_lds_sync();
     return h;
 }
 
-__device__ __forceinline__ float ksh_obs_value(const KshWaveLds &W, int f, float black_flag, float move_frac) {
-    const int p = (int)((unsigned)f / 81u);
-    const int s = f - 81 * p;
-    if (p < 28) return W.plane_of[s] == p ? 1.0f : 0.0f;
-    if (p < 42) return W.handv[p - 28];
-    if (p == 42) return black_flag;
-    if (p == 43) return move_frac;
-    return 0.0f;
+// Observation of the state in W.st32 (shogi/shogi_game_io.py:434-539), POV of the side to move, written with
+// coalesced 16-byte stores.  Planes 0-27 are one-hot piece planes: they are first collected as a 2 268-bit
+// set in LDS (one LDS atomic per piece) and expanded 4 bits -> 4 floats per lane; planes 28-45 are constant
+// per plane (hand counts / 18 and move_count / max_moves as the reference's double division rounded to
+// float32, the side-to-move flag, two zero planes).
+#define KSH_BOARD_F 2268  // 28 * 81
+__device__ __forceinline__ float ksh_obs_elem(const KshWaveLds &W, int f) {
+    if (f < KSH_BOARD_F) return ((W.obsbits[f >> 5] >> (f & 31)) & 1u) ? 1.0f : 0.0f;
+    return W.metav[(unsigned)(f - KSH_BOARD_F) / 81u];
+}
+__device__ __forceinline__ void ksh_write_obs(const KshBlockLds &L, KshWaveLds &W, const KshStepArgs &a, int g, int lane) {
+    const uint8_t *st8 = ST8(W);
+    const int side = st8[S_SIDE];
+    for (int i = lane; i < 80; i += 64) W.obsbits[i] = 0;
+    wave_lds_sync();
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const int s = pass * 64 + lane;
+        if (s < 81 && st8[s] != 0) {
+            const int pc = st8[s];
+            const int col = pc >= 15 ? 1 : 0;
+            const int t = pc - 1 - 14 * col;
+            const int bit = ((col == side ? 0 : 14) + t) * 81 + (side == 0 ? s : 80 - s);   // both r and c mirrored (:468-469)
+            atomicOr(&W.obsbits[bit >> 5], 1u << (bit & 31));
+        }
+    }
+    if (lane < 14) {
+        // planes 28-34 own hand, 35-41 opponent hand; count/18.0 in double, stored as float32 (:513-527)
+        const int cidx = lane < 7 ? side : 1 - side;
+        const int cnt = st8[S_HAND + 7 * cidx + (lane < 7 ? lane : lane - 7)];
+        W.metav[lane] = cnt < 32 ? L.tab.hand_lut[cnt] : (float)((double)cnt / 18.0);
+    } else if (lane == 14) {
+        W.metav[14] = side == 0 ? 1.0f : 0.0f;
+    } else if (lane == 15) {
+        // move_count / max_moves in double, stored as float32 (:535-536): host-built table, division only past its end
+        const int mcount = st8[S_MC] | (st8[S_MC + 1] << 8);
+        W.metav[15] = mcount == W.move_idx ? W.move_frac
+                                           : (a.max_moves > 0 ? (float)((double)mcount / (double)a.max_moves) : 0.0f);
+    } else if (lane < 20) {
+        W.metav[lane] = 0.0f;
+    }
+    wave_lds_sync();
+    // row g covers global floats [g*3726, (g+1)*3726); 3726 = 2 (mod 4): even rows start on a 16-byte
+    // boundary and end with half a chunk, odd rows start with the other half.
+    float *orow = a.obs + (size_t)g * KSH_OBSF;
+    const int head = (g & 1) ? 2 : 0;               // floats before the first fully aligned chunk
+    const int nfull = (KSH_OBSF - head) >> 2;       // 931 in both cases
+    const int nboard = (KSH_BOARD_F - head) >> 2;   // chunks lying entirely inside planes 0-27 (567 / 566)
+#pragma unroll
+    for (int it = 0; it < 9; it++) {                // 9 * 64 >= 567: constant trip count so the LDS reads batch up
+        const int c = lane + 64 * it;
+        if (c < nboard) {
+            const int f = head + 4 * c;
+            const uint32_t x = __funnelshift_r(W.obsbits[f >> 5], W.obsbits[(f >> 5) + 1], f & 31);
+            uint4 v;
+            v.x = (x & 1u) ? 0x3F800000u : 0u;
+            v.y = (x & 2u) ? 0x3F800000u : 0u;
+            v.z = (x & 4u) ? 0x3F800000u : 0u;
+            v.w = (x & 8u) ? 0x3F800000u : 0u;
+            *reinterpret_cast<uint4 *>(orow + f) = v;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 6; it++) {                // 6 * 64 >= 931 - 566
+        const int c = nboard + lane + 64 * it;
+        if (c < nfull) {
+            const int f = head + 4 * c;
+            float4 v;
+            if (f >= KSH_BOARD_F) {                 // at most two planes per chunk: two LDS reads + selects
+                const int p0 = (int)((unsigned)(f - KSH_BOARD_F) / 81u);
+                const int next = KSH_BOARD_F + 81 * (p0 + 1);
+                const float v0 = W.metav[p0], v1 = W.metav[p0 + 1 < 18 ? p0 + 1 : 17];
+                v = make_float4(v0, f + 1 < next ? v0 : v1, f + 2 < next ? v0 : v1, f + 3 < next ? v0 : v1);
+            } else {                                // the one chunk straddling plane 27 / 28
+                v = make_float4(ksh_obs_elem(W, f), ksh_obs_elem(W, f + 1), ksh_obs_elem(W, f + 2), ksh_obs_elem(W, f + 3));
+            }
+            *reinterpret_cast<float4 *>(orow + f) = v;
+        }
+    }
+    if (lane == 0) {
+        const int f = head ? 0 : 4 * nfull;         // the half chunk: floats 0,1 of an odd row / 3724,3725 of an even row
+        *reinterpret_cast<float2 *>(orow + f) = make_float2(ksh_obs_elem(W, f), ksh_obs_elem(W, f + 1));
+    }
 }
 
 extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(KshStepArgs a) {
@@ -455,31 +558,67 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
 #ifdef KSH_STAMPS
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
-    // stage the attack tables in LDS (24.8 KB, shared by the block's waves)
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // scalar: makes g and every address built from it uniform
+    const int g = blockIdx.x * KSH_WPB + wv;
+    const bool live = g < a.n_games;
+    // issue this game's global loads first so that their latency hides behind the table staging
+    uint32_t st_word = 0;
+    long long act = -1;
+    if (live) {
+        if (lane < 32) st_word = reinterpret_cast<const uint32_t *>(a.state + (size_t)g * 128)[lane];
+        if (a.mode == 2) act = a.actions[g];
+    }
+    // stage the attack tables in LDS (24.8 KB, shared by the block's waves): all loads in flight, then the stores
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.tables);
-        uint4 *dst = reinterpret_cast<uint4 *>(&L.tab);
-        for (int i = threadIdx.x; i < (int)(sizeof(KshTables) / 16); i += blockDim.x) dst[i] = src[i];
+        constexpr int NV = (int)(sizeof(KshTables) / 16);   // 1548 uint4 = 6 * 256 + 12
+        constexpr int NT = 64 * KSH_WPB;
+        static_assert(NV >= 6 * NT && NV < 7 * NT, "staging below is written for 6 full rounds + a remainder");
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.tables) + threadIdx.x;
+        uint4 *dst = reinterpret_cast<uint4 *>(&L.tab) + threadIdx.x;
+        const uint4 t0 = src[0], t1 = src[NT], t2 = src[2 * NT], t3 = src[3 * NT], t4 = src[4 * NT], t5 = src[5 * NT];
+        uint4 t6 = {0u, 0u, 0u, 0u};
+        const bool rem = (int)threadIdx.x < NV - 6 * NT;
+        if (rem) t6 = src[6 * NT];
+        dst[0] = t0; dst[NT] = t1; dst[2 * NT] = t2; dst[3 * NT] = t3; dst[4 * NT] = t4; dst[5 * NT] = t5;
+        if (rem) dst[6 * NT] = t6;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    const int g = blockIdx.x * KSH_WPB + wv;
-    if (g >= a.n_games) return;  // wave-uniform
+    if (!live) return;  // wave-uniform
     KshWaveLds &W = L.wave[wv];
     uint8_t *st8 = ST8(W);
 #ifdef KSH_STAMPS
-    if (lane == 0 && a.stamps) a.stamps[(size_t)g * 16 + 0] = t_entry;
+    if (lane == 0 && a.stamps) a.stamps[(size_t)g * 32 + 0] = t_entry;
 #endif
     KSH_STAMP(1);  // tables staged
 
-    // ---- load the state record, clear the legal bit-set
-    if (lane < 32) W.st32[lane] = reinterpret_cast<const uint32_t *>(a.state + (size_t)g * 128)[lane];
+    // ---- state record into LDS, clear the legal bit-set
+    if (lane < 32) W.st32[lane] = st_word;
     for (int i = lane; i < KSH_MASKW; i += 64) W.maskbits[i] = 0;
     wave_lds_sync();
 
+    // history prefetch (step mode): the entry this move will append is hidx = move_count - base
+    const int hidx = (int)(st8[S_MC] | (st8[S_MC + 1] << 8)) - (int)(st8[S_HBASE] | (st8[S_HBASE + 1] << 8));
+    const bool hist_ok = a.mode == 2 && hidx >= 0 && hidx < a.hist_cap;
+    unsigned long long *hrow = a.hist + (size_t)g * (size_t)a.hist_cap;
+    unsigned long long h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+    if (hist_ok) {
+        if (lane < hidx) h0 = hrow[lane];
+        if (64 + lane < hidx) h1 = hrow[64 + lane];
+        if (128 + lane < hidx) h2 = hrow[128 + lane];
+        if (192 + lane < hidx) h3 = hrow[192 + lane];
+    }
+    {
+        // move-count plane value of the state this launch will encode (after the move in step mode)
+        const int mc_enc = (int)(st8[S_MC] | (st8[S_MC + 1] << 8)) + ((a.mode == 2 && st8[S_OVER] == 0) ? 1 : 0);
+        float mf;
+        if (mc_enc < a.hist_cap) mf = a.move_lut[mc_enc];
+        else mf = a.max_moves > 0 ? (float)((double)mc_enc / (double)a.max_moves) : 0.0f;
+        if (lane == 0) { W.move_frac = mf; W.move_idx = mc_enc; }
+    }
     KSH_STAMP(2);  // state loaded
     int out_done = 0, out_reason = 0, out_winner = -1, n_out = 0;
+    bool obs_written = false;
     float out_reward = 0.0f;
     bool need_gen = true;
 
@@ -494,7 +633,6 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
     int me = st8[S_SIDE];
     if (a.mode == 2) {
         const int mover = me;
-        const long long act = a.actions[g];
         const bool over = st8[S_OVER] != 0;
         if (over) {
             // stepping a finished game (no auto-reset): nothing moves (shogi_game.py:589-593)
@@ -565,28 +703,36 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
                 wave_lds_sync();
                 me = 1 - mover;
                 const int mc = st8[S_MC] | (st8[S_MC + 1] << 8);
-                const int hbase = st8[S_HBASE] | (st8[S_HBASE + 1] << 8);
                 KSH_STAMP(3);  // move applied
-                // ---- position key of the post-move state, appended to the game's history
+                // ---- position key of the post-move state, appended to the game's history.  All global LOADS of
+                // this wave happen before its first observation store: on gfx9 loads and stores share one in-order
+                // vmcnt, so a load waited on after the stores would stall until the stores have drained.
                 const unsigned long long h = ksh_hash(W, lane);
-                KSH_STAMP(4);  // hashed
-                const int idx = mc - 1 - hbase;
-                unsigned long long *hrow = a.hist + (size_t)g * (size_t)a.hist_cap;
                 int rep = 1;
-                if (idx >= 0 && idx < a.hist_cap) {
-                    if (lane == 0) hrow[idx] = h;
-                    int matches = 0;
-                    for (int base = 0; base < idx; base += 64) {  // bounded: idx < hist_cap
+                if (hist_ok) {
+                    if (lane == 0) hrow[hidx] = h;
+                    int matches = __popcll(__ballot(lane < hidx && h0 == h)) + __popcll(__ballot(64 + lane < hidx && h1 == h)) +
+                                  __popcll(__ballot(128 + lane < hidx && h2 == h)) + __popcll(__ballot(192 + lane < hidx && h3 == h));
+                    for (int base = 256; base < hidx; base += 64) {  // bounded: hidx < hist_cap
                         const int i = base + lane;
-                        const bool m = (i < idx) && hrow[i] == h;
+                        const bool m = (i < hidx) && hrow[i] == h;
                         matches += __popcll(__ballot(m));
                     }
                     rep += matches;
                 }
-                KSH_STAMP(5);  // history scanned
+                KSH_STAMP(4);  // hashed + history scanned
+                // ---- observation of the post-move state: issued NOW so the stores drain while the move
+                // generator runs; rewritten below in the rare case the game ends and is reset
+                ksh_write_obs(L, W, a, g, lane);
+                obs_written = true;
+                KSH_STAMP(5);  // obs stores issued
                 // ---- legal moves of the side now to move (+ nested uchi-fu-zume reply search)
                 bool chk;
+#ifdef KSH_STAMPS
+                int n = ksh_gen_full(L, W, lane, me, chk, a.stamps ? a.stamps + (size_t)g * 32 + 16 : nullptr);
+#else
                 int n = ksh_gen_full(L, W, lane, me, chk);
+#endif
                 KSH_STAMP(6);  // movegen done
                 need_gen = false;
                 n_out = n;
@@ -609,6 +755,7 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
                         wave_lds_sync();
                         me = 0;
                         need_gen = true;
+                        obs_written = false;   // the observation must show the reset position
                     } else if (lane == 0) {
                         st8[S_OVER] = 1;
                         st8[S_REASON] = (uint8_t)out_reason;
@@ -638,54 +785,9 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
         a.winner[g] = (signed char)out_winner;
     }
 
-    // ---- observation (shogi_game_io.py:434-539), POV of the side to move, coalesced 16-byte stores
-    const int side = st8[S_SIDE];
-    W.plane_of[lane] = 0xFF;
-    if (lane < 32) W.plane_of[64 + lane] = 0xFF;
-    wave_lds_sync();
-#pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-        const int s = pass * 64 + lane;
-        if (s < 81 && st8[s] != 0) {
-            const int pc = st8[s];
-            const int col = pc >= 15 ? 1 : 0;
-            const int t = pc - 1 - 14 * col;
-            W.plane_of[side == 0 ? s : 80 - s] = (uint8_t)((col == side ? 0 : 14) + t);
-        }
-    }
-    if (lane < 14) {
-        // planes 28-34 own hand, 35-41 opponent hand; count/18.0 in double, stored as float32 (:513-527)
-        const int cidx = lane < 7 ? side : 1 - side;
-        const int cnt = st8[S_HAND + 7 * cidx + (lane < 7 ? lane : lane - 7)];
-        W.handv[lane] = (float)((double)cnt / 18.0);
-    }
-    wave_lds_sync();
-    KSH_STAMP(8);  // obs tables built
-    const float black_flag = side == 0 ? 1.0f : 0.0f;
-    const int mcount = st8[S_MC] | (st8[S_MC + 1] << 8);
-    const float move_frac = a.max_moves > 0 ? (float)((double)mcount / (double)a.max_moves) : 0.0f;
-    {
-        // row g covers global floats [g*3726, (g+1)*3726); 3726 = 2 (mod 4): even rows start on a
-        // 16-byte boundary and end with half a chunk, odd rows start with the other half.
-        float *orow = a.obs + (size_t)g * KSH_OBSF;
-        const int head = (g & 1) ? 2 : 0;  // floats before the first fully aligned chunk
-        if (head && lane == 0) {
-            float2 v = make_float2(ksh_obs_value(W, 0, black_flag, move_frac), ksh_obs_value(W, 1, black_flag, move_frac));
-            *reinterpret_cast<float2 *>(orow) = v;
-        }
-        const int nfull = (KSH_OBSF - head) >> 2;  // 931 in both cases
-        for (int c = lane; c < nfull; c += 64) {
-            const int f = head + 4 * c;
-            float4 v = make_float4(ksh_obs_value(W, f, black_flag, move_frac), ksh_obs_value(W, f + 1, black_flag, move_frac),
-                                   ksh_obs_value(W, f + 2, black_flag, move_frac), ksh_obs_value(W, f + 3, black_flag, move_frac));
-            *reinterpret_cast<float4 *>(orow + f) = v;
-        }
-        if (!head && lane == 0) {
-            const int f = 4 * nfull;  // 3724
-            float2 v = make_float2(ksh_obs_value(W, f, black_flag, move_frac), ksh_obs_value(W, f + 1, black_flag, move_frac));
-            *reinterpret_cast<float2 *>(orow + f) = v;
-        }
-    }
+    // ---- observation, unless it was already issued right after the move
+    KSH_STAMP(8);
+    if (!obs_written) ksh_write_obs(L, W, a, g, lane);
 
     KSH_STAMP(9);  // obs stores issued
     // ---- legal mask: expand the bit-set to one byte per action, 16-byte aligned stores
@@ -696,16 +798,20 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
         const int nfull = (KSH_A - head) >> 4;
         const int tail0 = head + 16 * nfull;                     // first byte of the ragged tail
         if (lane < head) mrow[lane] = (uint8_t)((W.maskbits[0] >> lane) & 1u);
-        for (int c = lane; c < nfull; c += 64) {
-            const int b0 = head + 16 * c;
-            const uint32_t lo = W.maskbits[b0 >> 5], hi = W.maskbits[(b0 >> 5) + 1];
-            const uint32_t x = __funnelshift_r(lo, hi, b0 & 31);  // 32 bits starting at bit b0
-            uint4 v;
-            v.x = __umul24(x & 0xFu, 0x204081u) & 0x01010101u;    // 4 bits -> 4 bytes of 0/1
-            v.y = __umul24((x >> 4) & 0xFu, 0x204081u) & 0x01010101u;
-            v.z = __umul24((x >> 8) & 0xFu, 0x204081u) & 0x01010101u;
-            v.w = __umul24((x >> 12) & 0xFu, 0x204081u) & 0x01010101u;
-            *reinterpret_cast<uint4 *>(mrow + b0) = v;
+#pragma unroll
+        for (int it = 0; it < 14; it++) {                         // 14 * 64 >= 845: constant trip count
+            const int c = lane + 64 * it;
+            if (c < nfull) {
+                const int b0 = head + 16 * c;
+                const uint32_t lo = W.maskbits[b0 >> 5], hi = W.maskbits[(b0 >> 5) + 1];
+                const uint32_t x = __funnelshift_r(lo, hi, b0 & 31);  // 32 bits starting at bit b0
+                uint4 v;
+                v.x = __umul24(x & 0xFu, 0x204081u) & 0x01010101u;    // 4 bits -> 4 bytes of 0/1
+                v.y = __umul24((x >> 4) & 0xFu, 0x204081u) & 0x01010101u;
+                v.z = __umul24((x >> 8) & 0xFu, 0x204081u) & 0x01010101u;
+                v.w = __umul24((x >> 12) & 0xFu, 0x204081u) & 0x01010101u;
+                *reinterpret_cast<uint4 *>(mrow + b0) = v;
+            }
         }
         const int ntail = KSH_A - tail0;
         if (lane < ntail) {

@@ -36,6 +36,7 @@ struct KshEnv {
     uint8_t *state;
     unsigned long long *hist;
     KshTables *tables;
+    float *move_lut;
 };
 
 extern "C" {
@@ -54,6 +55,7 @@ int ksh_env_create(int device, int n_games, int max_moves, void **handle) {
     e->state = nullptr;
     e->hist = nullptr;
     e->tables = nullptr;
+    e->move_lut = nullptr;
     KshTables *t = new KshTables();
     ksh_build_tables(t);
     hipError_t err = hipMalloc(&e->state, (size_t)n_games * 128);
@@ -65,12 +67,19 @@ int ksh_env_create(int device, int n_games, int max_moves, void **handle) {
         for (int g = 0; g < n_games; g++) memcpy(&init[(size_t)g * 128], t->init_state, 128);
         err = hipMemcpy(e->state, init.data(), init.size(), hipMemcpyHostToDevice);
     }
+    if (err == hipSuccess) err = hipMalloc(&e->move_lut, (size_t)e->hist_cap * sizeof(float));
+    if (err == hipSuccess) {
+        std::vector<float> lut((size_t)e->hist_cap);
+        for (int i = 0; i < e->hist_cap; i++) lut[i] = (float)((double)i / (double)max_moves);  // shogi_game_io.py:535-536
+        err = hipMemcpy(e->move_lut, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
     if (err == hipSuccess) err = hipMemset(e->hist, 0, (size_t)n_games * e->hist_cap * sizeof(unsigned long long));
     delete t;
     if (err != hipSuccess) {
         if (e->state) (void)hipFree(e->state);
         if (e->hist) (void)hipFree(e->hist);
         if (e->tables) (void)hipFree(e->tables);
+        if (e->move_lut) (void)hipFree(e->move_lut);
         delete e;
         return fail_hip(err, "ksh_env_create");
     }
@@ -84,6 +93,7 @@ int ksh_env_destroy(void *handle) {
     (void)hipFree(e->state);
     (void)hipFree(e->hist);
     (void)hipFree(e->tables);
+    (void)hipFree(e->move_lut);
     delete e;
     return KSH_OK;
 }
@@ -103,6 +113,7 @@ static int launch_env(KshEnv *e, int mode, const int64_t *actions, const uint8_t
     a.state = e->state;
     a.hist = e->hist;
     a.tables = e->tables;
+    a.move_lut = e->move_lut;
     a.actions = reinterpret_cast<const long long *>(actions);
     a.prev_mask = prev_mask;
     a.reset_mask = reset_mask;

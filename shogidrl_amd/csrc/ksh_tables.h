@@ -17,7 +17,7 @@ struct KshTables {
     uint32_t ray[8][81][4];    // [dir][sq] -> {w0,w1,w2,0}: squares from sq (exclusive) to the edge
     uint32_t step[11][81][4];  // [class][sq] -> {w0,w1,w2,0}
     uint8_t init_state[128];   // packed initial position (shogi_game.py:79-130)
-    uint8_t pad[16];
+    float hand_lut[32];        // (float)((double)count / 18.0), the hand-plane value (shogi_game_io.py:513-527)
 };
 static_assert(sizeof(KshTables) % 16 == 0, "tables are copied to LDS as uint4");
 
@@ -68,4 +68,5 @@ static inline void ksh_build_tables(KshTables *t) {
     b[1 * 9 + 7] = 1 + 5 + 14;
     b[7 * 9 + 1] = 1 + 5;
     b[7 * 9 + 7] = 1 + 6;
+    for (int i = 0; i < 32; i++) t->hand_lut[i] = (float)((double)i / 18.0);
 }

@@ -111,3 +111,6 @@ struct bf16 {
 };
 }  // namespace emu
 #define __bf16 emu::bf16
+// value of the first lane of the wave (all lanes are active wherever the kernels use it)
+#define __builtin_amdgcn_readfirstlane(x) (__shfl((int)(x), 0))
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)

@@ -27,10 +27,12 @@ logits = torch.zeros(N, 13527, device="cuda:0")
 for t in range(80):
     a, _ = ops.masked_sample(logits, env.legal_mask, 42, t)
     env.step(a, validate=False)
-st = torch.zeros(N, 16, dtype=torch.int64, device="cuda:0")
+st = torch.zeros(N, 32, dtype=torch.int64, device="cuda:0")
 L.ksh_debug_set_stamps(st.data_ptr())
 names = ["entry", "tables", "state", "applied", "hashed", "hist", "movegen", "term/regen", "obs tbl", "obs st", "mask st"]
 acc = np.zeros((10,), np.float64)
+gacc = np.zeros((7,), np.float64)
+nested = 0.0
 span = 0.0
 reps = 20
 for t in range(reps):
@@ -42,9 +44,18 @@ for t in range(reps):
     ok = (s[:, 3] > 0)
     d = np.diff(s[ok][:, :11], axis=1)
     acc += np.median(d, axis=0)
+    gs = s[ok]
+    # inside the first move generation: stamps 16+11..16+15, end of main gen at 16+10, flag nested at 16+9
+    seq = np.stack([gs[:, 5], gs[:, 27], gs[:, 28], gs[:, 29], gs[:, 30], gs[:, 31], gs[:, 26], gs[:, 6]], axis=1)
+    gacc += np.median(np.diff(seq, axis=1), axis=0)
+    nested += gs[:, 25].mean()
     span += (s[:, 10].max() - s[:, 0].min())
 L.ksh_debug_set_stamps(None)
 print("N=%d median per-wave phase durations (s_memtime ticks = 100 MHz? or shader clk), avg over %d steps" % (N, reps))
 for i in range(10):
     print("  %-12s -> %-12s %9.1f" % (names[i], names[i + 1], acc[i] / reps))
 print("  sum %.1f ; kernel span (first entry -> last end) %.1f" % (acc.sum() / reps, span / reps))
+gn = ["obs issued->ballots+compact", "attack sets", "reductions+checkers", "pins+block", "board emit", "drops+count (main gen end)", "ufz nested + rest"]
+for i in range(7):
+    print("    gen: %-30s %9.1f" % (gn[i], gacc[i] / reps))
+print("    fraction of positions needing the nested uchi-fu-zume search: %.3f" % (nested / reps))
