@@ -192,12 +192,14 @@ int ksh_masked_sample(const void *logits, int logits_dtype, const uint8_t *mask,
                       int deterministic, int64_t *action, float *log_prob, void *stream) {
     if (!logits || !mask || !action || !log_prob || B <= 0) return fail_arg("ksh_masked_sample: bad argument");
     if (logits_dtype != 0 && logits_dtype != 1) return fail_arg("ksh_masked_sample: logits_dtype must be 0 (f32) or 1 (bf16)");
+    const dim3 grid((B + KSH_SAMPLE_WPB - 1) / KSH_SAMPLE_WPB), block(64 * KSH_SAMPLE_WPB);
     if (logits_dtype == 0)
-        hipLaunchKernelGGL(ksh_masked_sample_kernel<float>, dim3(B), dim3(KSH_ROW_THREADS), 0, (hipStream_t)stream,
-                           (const float *)logits, mask, seed, step, deterministic, reinterpret_cast<long long *>(action), log_prob);
+        hipLaunchKernelGGL(ksh_masked_sample_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float *)logits, mask,
+                           B, seed, step, deterministic, reinterpret_cast<long long *>(action), log_prob);
     else
-        hipLaunchKernelGGL(ksh_masked_sample_kernel<ksh_bf16>, dim3(B), dim3(KSH_ROW_THREADS), 0, (hipStream_t)stream,
-                           (const ksh_bf16 *)logits, mask, seed, step, deterministic, reinterpret_cast<long long *>(action), log_prob);
+        hipLaunchKernelGGL(ksh_masked_sample_kernel<ksh_bf16>, grid, block, 0, (hipStream_t)stream,
+                           (const ksh_bf16 *)logits, mask, B, seed, step, deterministic,
+                           reinterpret_cast<long long *>(action), log_prob);
     HIP_TRY(hipGetLastError());
     return KSH_OK;
 }

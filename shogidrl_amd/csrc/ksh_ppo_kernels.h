@@ -225,44 +225,99 @@ __device__ __forceinline__ uint32_t ksh_philox(uint32_t c0, uint32_t c1, uint32_
 // G_j = -log(-log u_j), u_j from Philox keyed by (seed; action, row, step) -- order independent, so the
 // result is a pure function of (seed, step, row, logits, mask).  log_prob follows
 // Categorical(probs=softmax(masked logits)).log_prob: log(clamp(p, eps, 1-eps)).
+//
+// One WAVE per row (4 rows per block, no block barrier): each lane streams 14 aligned 16-byte chunks of the
+// mask row (all loads in flight), and only for non-zero bytes gathers the logit -- a real position has ~50
+// legal actions out of 13 527, so the logits of illegal actions are never read.
+#define KSH_SAMPLE_WPB 4
+
+struct KshSampleAcc {
+    float m, s, key, zbest;
+    int idx;
+};
+
 template <typename T>
-__global__ void __launch_bounds__(KSH_ROW_THREADS)
-ksh_masked_sample_kernel(const T *__restrict__ logits, const uint8_t *__restrict__ mask, unsigned long long seed,
+__device__ __forceinline__ void ksh_sample_visit(KshSampleAcc &A, const T *row, int j, int b, bool deterministic,
+                                                 uint32_t s0, uint32_t s1, uint32_t k0, uint32_t k1) {
+    const float z = ksh_ld(row + j);
+    ksh_ms_merge(A.m, A.s, z, 1.0f);
+    float k = z;
+    if (!deterministic) {
+        const uint32_t x = ksh_philox((uint32_t)j, (uint32_t)b, s0, s1, k0, k1);
+        const float u = ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
+        k = z - logf(-logf(u));
+    }
+    if (A.idx < 0 || k > A.key || (k == A.key && j < A.idx)) { A.key = k; A.idx = j; A.zbest = z; }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64 * KSH_SAMPLE_WPB)
+ksh_masked_sample_kernel(const T *__restrict__ logits, const uint8_t *__restrict__ mask, int B, unsigned long long seed,
                          unsigned long long step, int deterministic, long long *__restrict__ action,
                          float *__restrict__ log_prob) {
-    __shared__ KshRowLds R;
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x;
-    ksh_build_bits(R, mask + (size_t)b * KSH_PA, tid);
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * KSH_SAMPLE_WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (b >= B) return;  // wave-uniform
+    const uint8_t *mrow = mask + (size_t)b * KSH_PA;
     const T *row = logits + (size_t)b * KSH_PA;
-    float m = -INFINITY, s = 0.0f, key = -INFINITY, zbest = 0.0f;
-    int idx = -1;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const uint32_t s0 = (uint32_t)step, s1 = (uint32_t)(step >> 32);
-    ksh_for_each_legal<T>(row, R.bits, tid, [&](int j, float z) {
-        ksh_ms_merge(m, s, z, 1.0f);
-        float k = z;
-        if (!deterministic) {
-            const uint32_t x = ksh_philox((uint32_t)j, (uint32_t)b, s0, s1, k0, k1);
-            const float u = ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
-            k = z - logf(-logf(u));
+    const bool det = deterministic != 0;
+    KshSampleAcc A = {-INFINITY, 0.0f, -INFINITY, 0.0f, -1};
+
+    const size_t addr = reinterpret_cast<size_t>(mrow);
+    const int head = (int)((16 - (addr & 15)) & 15);
+    const int nfull = (KSH_PA - head) >> 4;               // 844 or 845 aligned chunks
+    const int tail0 = head + 16 * nfull;
+    if (lane < head && mrow[lane]) ksh_sample_visit<T>(A, row, lane, b, det, s0, s1, k0, k1);
+    if (lane < KSH_PA - tail0 && mrow[tail0 + lane]) ksh_sample_visit<T>(A, row, tail0 + lane, b, det, s0, s1, k0, k1);
+#pragma unroll
+    for (int half = 0; half < 2; half++) {                 // 2 x 7 x 64 = 896 >= 845 chunks, 7 loads in flight per lane
+        uint4 ch[7];
+#pragma unroll
+        for (int it = 0; it < 7; it++) {
+            const int c = lane + 64 * (7 * half + it);
+            ch[it] = uint4{0u, 0u, 0u, 0u};
+            if (c < nfull) ch[it] = *reinterpret_cast<const uint4 *>(mrow + head + 16 * c);
         }
-        if (idx < 0 || k > key || (k == key && j < idx)) { key = k; idx = j; zbest = z; }
-    });
-    ksh_block_ms(R, m, s, tid);
-    ksh_block_argmax(R, key, idx, zbest, tid);
-    if (tid == 0) {
+#pragma unroll
+        for (int it = 0; it < 7; it++) {
+            const uint32_t any = ch[it].x | ch[it].y | ch[it].z | ch[it].w;
+            if (any != 0u) {
+                const int j0 = head + 16 * (lane + 64 * (7 * half + it));
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    uint32_t v = q == 0 ? ch[it].x : (q == 1 ? ch[it].y : (q == 2 ? ch[it].z : ch[it].w));
+                    while (v) {                             // visit the non-zero bytes of this dword
+                        const int byte = (__ffs((int)v) - 1) >> 3;
+                        v &= ~(0xFFu << (8 * byte));
+                        ksh_sample_visit<T>(A, row, j0 + 4 * q + byte, b, det, s0, s1, k0, k1);
+                    }
+                }
+            }
+        }
+    }
+    // wave reductions (xor butterfly): soft-max statistics and the arg-max with its logit
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float m2 = __shfl_xor(A.m, o), s2 = __shfl_xor(A.s, o);
+        ksh_ms_merge(A.m, A.s, m2, s2);
+        const float k2 = __shfl_xor(A.key, o), z2 = __shfl_xor(A.zbest, o);
+        const int i2 = __shfl_xor(A.idx, o);
+        if (i2 >= 0 && (A.idx < 0 || k2 > A.key || (k2 == A.key && i2 < A.idx))) { A.key = k2; A.idx = i2; A.zbest = z2; }
+    }
+    if (lane == 0) {
         long long a;
         float lp;
-        if (idx < 0) {
+        if (A.idx < 0) {
             // no legal action: the reference falls back to a uniform distribution over ALL actions
             // (base_actor_critic.py:93-101)
             const uint32_t x = ksh_philox(0xFFFFFFFFu, (uint32_t)b, s0, s1, k0, k1);
-            a = deterministic ? 0 : (long long)(((unsigned long long)x * (unsigned long long)KSH_PA) >> 32);
+            a = det ? 0 : (long long)(((unsigned long long)x * (unsigned long long)KSH_PA) >> 32);
             lp = logf(1.0f / (float)KSH_PA);
         } else {
-            a = idx;
-            float p = expf(zbest - m) / s;
+            a = A.idx;
+            float p = expf(A.zbest - A.m) / A.s;
             p = fminf(fmaxf(p, KSH_EPS), 1.0f - KSH_EPS);
             lp = logf(p);
         }

@@ -7,10 +7,10 @@ namespace {
 struct GaeA { const float *r, *v; const uint8_t *d; const float *lv; float g, gl; int T, N; float *adv, *ret; } ga;
 void gae_entry(void *) { ksh_gae_kernel(ga.r, ga.v, ga.d, ga.lv, ga.g, ga.gl, ga.T, ga.N, ga.adv, ga.ret); }
 
-struct SampA { const void *logits; int dtype; const uint8_t *mask; unsigned long long seed, step; int det; long long *act; float *lp; } sa;
+struct SampA { const void *logits; int dtype; const uint8_t *mask; int B; unsigned long long seed, step; int det; long long *act; float *lp; } sa;
 void samp_entry(void *) {
-    if (sa.dtype == 0) ksh_masked_sample_kernel<float>((const float *)sa.logits, sa.mask, sa.seed, sa.step, sa.det, sa.act, sa.lp);
-    else ksh_masked_sample_kernel<ksh_bf16>((const ksh_bf16 *)sa.logits, sa.mask, sa.seed, sa.step, sa.det, sa.act, sa.lp);
+    if (sa.dtype == 0) ksh_masked_sample_kernel<float>((const float *)sa.logits, sa.mask, sa.B, sa.seed, sa.step, sa.det, sa.act, sa.lp);
+    else ksh_masked_sample_kernel<ksh_bf16>((const ksh_bf16 *)sa.logits, sa.mask, sa.B, sa.seed, sa.step, sa.det, sa.act, sa.lp);
 }
 KshLossArgs la;
 const void *l_logits; void *l_dlogits; int l_dtype;
@@ -29,8 +29,8 @@ void emu_gae(const float *r, const float *v, const uint8_t *d, const float *lv, 
 }
 void emu_masked_sample(const void *logits, int dtype, const uint8_t *mask, int B, unsigned long long seed,
                        unsigned long long step, int det, long long *action, float *logp) {
-    sa = SampA{logits, dtype, mask, seed, step, det, action, logp};
-    for (int b = 0; b < B; b++) emu::run_block(samp_entry, nullptr, b, KSH_ROW_THREADS);
+    sa = SampA{logits, dtype, mask, B, seed, step, det, action, logp};
+    for (int b = 0; b < (B + KSH_SAMPLE_WPB - 1) / KSH_SAMPLE_WPB; b++) emu::run_block(samp_entry, nullptr, b, 64 * KSH_SAMPLE_WPB);
 }
 void emu_ppo_loss(const void *logits, int dtype, const uint8_t *mask, const long long *actions, const float *old_logp,
                   const float *adv, const float *ret, const float *values, const float *old_values, int B, float clip_eps,

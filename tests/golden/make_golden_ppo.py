@@ -209,3 +209,57 @@ if __name__ == "__main__":
     make_gae()
     make_ppo_loss()
     make_sample()
+
+
+# ------------------------------------------------------------------------------- learn() end to end
+def make_learn_e2e():
+    """PPOAgent.learn on a small real network: metrics + (clipped) gradients of the single update.
+    Both sides build the network from torch.manual_seed(7) with identical module order, so the initial
+    weights agree without shipping them; a few checksums of the initial weights are stored to prove it."""
+    from keisei.training.models.resnet_tower import ActorCriticResTower
+    rng = np.random.default_rng(77)
+    B = 8
+    obs = (rng.random((B, 46, 9, 9)) < 0.05).astype(np.float32)
+    mask = np.zeros((B, A), bool)
+    actions = np.zeros(B, np.int64)
+    for b in range(B):
+        ids = np.sort(rng.choice(A, int(rng.choice([3, 30, 80])), replace=False))
+        mask[b, ids] = True
+        actions[b] = ids[rng.integers(len(ids))]
+    old_logp = rng.normal(-3.0, 0.3, B).astype(np.float32)
+    old_values = rng.normal(0, 0.5, B).astype(np.float32)
+    adv = rng.normal(0, 1, B).astype(np.float32)
+    ret = rng.normal(0, 1, B).astype(np.float32)
+    out = {}
+    for name, epochs, mb, normalize in (("one_update", 1, 8, False), ("two_epochs_mb4_norm", 2, 4, True)):
+        torch.manual_seed(7)
+        model = ActorCriticResTower(46, A, tower_depth=2, tower_width=16, se_ratio=0.25)
+        init_sums = np.asarray([float(p.detach().double().sum()) for p in model.parameters()])
+        cfg = load_config()
+        cfg.training.ppo_epochs = epochs
+        cfg.training.minibatch_size = mb
+        cfg.training.normalize_advantages = normalize
+        cfg.training.enable_value_clipping = False
+        cfg.training.lr_schedule_type = None
+        cfg.env.device = "cpu"
+        cfg.env.seed = 42
+        agent = PPOAgent(model, cfg, torch.device("cpu"))
+        buf = ExperienceBuffer(B, 0.99, 0.95, "cpu")
+        for b in range(B):
+            buf.add(torch.tensor(obs[b]), int(actions[b]), 0.0, float(old_logp[b]), float(old_values[b]), False,
+                    torch.tensor(mask[b]))
+        buf.compute_advantages_and_returns(0.0)
+        buf.advantages[:] = torch.tensor(adv)
+        buf.returns[:] = torch.tensor(ret)
+        metrics = agent.learn(buf)
+        out[f"{name}_metrics"] = np.asarray([metrics["ppo/policy_loss"], metrics["ppo/value_loss"], metrics["ppo/entropy"],
+                                             metrics["ppo/kl_divergence_approx"], metrics["ppo/clip_fraction"]], np.float64)
+        out[f"{name}_init_sums"] = init_sums
+        # gradients of the LAST update after clip_grad_norm_ (in place): first 32 entries of every tensor + norms
+        out[f"{name}_grad_head"] = np.concatenate([p.grad.detach().reshape(-1)[:32].numpy() for p in model.parameters()])
+        out[f"{name}_grad_norms"] = np.asarray([float(p.grad.detach().norm()) for p in model.parameters()])
+        out[f"{name}_last_gradient_norm"] = np.asarray(agent.last_gradient_norm)
+        print("learn_e2e", name, out[f"{name}_metrics"], agent.last_gradient_norm)
+    np.savez_compressed(os.path.join(HERE, "learn_e2e.npz"), obs_packed=np.packbits(obs.astype(bool).reshape(B, -1), axis=1),
+                        mask_packed=np.packbits(mask, axis=1, bitorder="little"), actions=actions, old_logp=old_logp,
+                        old_values=old_values, adv=adv, ret=ret, **out)

@@ -1,0 +1,89 @@
+"""N > 1 host logic of the data-parallel path on CPU: world_size-2 gloo processes exercise game sharding,
+the flat-gradient all-reduce and the 3-moment advantage all-reduce of shogidrl_amd.parallel and check that
+the 2-rank result equals the 1-rank result on the concatenated batch."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from shogidrl_amd import parallel
+
+
+def test_shard_range_partitions_exactly():
+    for n, w in ((4096, 8), (10, 3), (7, 8), (32768, 8)):
+        spans = [parallel.shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, lr, w = parallel.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.Flatten(), torch.nn.Linear(4 * 9, 2))
+    model = model.to(memory_format=torch.channels_last)
+    bucket = parallel.FlatGradBucket(model.parameters())
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(8, 3, 3, 3, generator=g)
+    y = torch.randn(8, 2, generator=g)
+    lo, hi = parallel.shard_range(8, rank, world)
+    bucket.zero()
+    loss = ((model(x[lo:hi]) - y[lo:hi]) ** 2).mean()
+    loss.backward()
+    bucket.all_reduce_mean()
+    adv = torch.arange(8, dtype=torch.float32) ** 1.5
+    n, mean, std = parallel.global_advantage_moments(adv[lo:hi])
+    m = parallel.all_reduce_mean_(torch.tensor([float(rank)]))
+    parallel.broadcast_parameters(model, src=0)
+    q.put((rank, bucket.flat.clone(), float(n), float(mean), float(std), float(m)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_equals_single_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference on the concatenated batch
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.Flatten(), torch.nn.Linear(4 * 9, 2))
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(8, 3, 3, 3, generator=g)
+    y = torch.randn(8, 2, generator=g)
+    loss = ((model(x) - y) ** 2).mean()
+    loss.backward()
+    want = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    for rank, flat, n, mean, std, m in res:
+        # the bucket keeps each gradient in the parameter's own (channels_last) layout: compare as sets of values per tensor
+        off = 0
+        for p in model.parameters():
+            got = flat[off:off + p.numel()].as_strided(p.size(), p.contiguous(memory_format=torch.channels_last).stride()
+                                                         if p.dim() == 4 else p.stride())
+            assert torch.allclose(got, p.grad, atol=1e-6), rank
+            off += p.numel()
+        adv = torch.arange(8, dtype=torch.float32) ** 1.5
+        assert n == 8 and abs(mean - float(adv.mean())) < 1e-6 and abs(std - float(adv.std())) < 1e-5
+        assert m == 0.5
+    assert torch.equal(res[0][1], res[1][1])
+    assert want.numel() == res[0][1].numel()
