@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libkeisei_hip.so")
+# SHOGIDRL_AMD_LIB lets a developer point at an alternative build of the SAME library (diagnostic / A-B builds)
+LIB_PATH = os.environ.get("SHOGIDRL_AMD_LIB") or os.path.join(PKG, "libkeisei_hip.so")
 
 NUM_ACTIONS = 13527
 OBS_SHAPE = (46, 9, 9)

@@ -37,12 +37,13 @@
 #define S_REASON 99
 #define S_WINNER 100
 #define S_HBASE 102
+#define S_HASH KSH_S_HASH      // 8 bytes: position key of the current state
+#define S_NFRAC KSH_S_NFRAC    // float: (move_count + 1) / max_moves
 
 struct KshStepArgs {
     uint8_t *state;            // [N][128]
     unsigned long long *hist;  // [N][hist_cap] position hashes of post-move states
     const KshTables *tables;
-    const float *move_lut;     // [hist_cap]: (float)((double)i / (double)max_moves), the move-count plane value
     const long long *actions;  // [N] or null (mode != 2)
     const uint8_t *prev_mask;  // [N][A] or null
     const uint8_t *reset_mask; // [N] or null (mode 1)
@@ -141,11 +142,6 @@ __device__ __forceinline__ int sq_dir(int a, int b) {
     return -1;
 }
 
-__device__ __forceinline__ uint32_t fmix32(uint32_t x) {
-    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
-    return x;
-}
-
 // Compiler-level ordering point for LDS traffic between lanes of ONE wave.  The hardware executes a
 // wave's DS instructions in order, so no instruction is needed; this only pins the order in the IR.
 __device__ __forceinline__ void wave_lds_sync() {
@@ -173,17 +169,25 @@ __device__ __forceinline__ int wave_sum_small(int v) {
     return s;
 }
 
+// 16-byte store of an output row chunk; -DKSH_NT_STORES selects the non-temporal form (A/B experiment).
+typedef uint32_t ksh_u32x4 __attribute__((vector_size(16)));
+__device__ __forceinline__ void ksh_store16(void *p, uint4 v) {
+#ifdef KSH_NT_STORES
+    ksh_u32x4 q = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(q, reinterpret_cast<ksh_u32x4 *>(p));
+#else
+    *reinterpret_cast<uint4 *>(p) = v;
+#endif
+}
+
 // per-wave LDS scratch
 struct KshWaveLds {
     uint32_t maskbits[KSH_MASKW];  // legal action bit-set, bit i <-> action id i
     uint32_t st32[32];             // the 128-byte state record
     uint8_t plist[64];             // squares of the pieces on the board (compacted)
-    uint8_t pin_dir[96];           // per square: ray direction (from the king) it is pinned along, 0xFF none
     uint32_t obsbits[80];          // planes 0-27 of the observation as a bit-set: bit plane*81 + pov_sq (2268 bits)
     float metav[20];               // planes 28-45: hands (own P..R, opp P..R), side-to-move flag, move fraction, 0, 0
-    float move_frac;               // move-count plane value prefetched for move count move_idx
-    int move_idx;
-    uint32_t pad_[6];
+    uint32_t pad_[8];
 };
 
 struct KshBlockLds {
@@ -207,6 +211,43 @@ __device__ __forceinline__ BB3 lds_bb(const uint32_t (*tbl)[81][4], int k, int s
 // move is already in check (hand-made positions only) the reference's test "the king is attacked
 // after the drop" (shogi_rules_logic.py:329-332) holds for every pawn drop, so all of them are.
 // ------------------------------------------------------------------------------------------------
+
+// ---- emission helpers: the action ids of one from-square are the 160 consecutive bits [160*from, 160*from+160)
+// of the legal bit-set (utils/utils.py:208-241: id = ((from*80 + to - (to > from))*2 + promote), i.e. exactly five
+// dwords that no other piece writes.  They are built without loops: the 81-bit target sets (non-promoting /
+// promoting) are made contiguous, the from-square is squeezed out window by window, and the two sets are
+// bit-interleaved.
+struct Stream81 {
+    uint32_t c0, c1, c2;
+};
+__device__ __forceinline__ Stream81 bb_stream(BB3 b) {
+    return Stream81{b.w0 | (b.w1 << 27), (b.w1 >> 5) | (b.w2 << 22), b.w2 >> 10};
+}
+// 16 bits starting at (compile-time) bit p of the stream
+template <int P>
+__device__ __forceinline__ uint32_t stream_ext16(Stream81 x) {
+    constexpr int w = P >> 5, sh = P & 31;
+    const uint32_t lo = w == 0 ? x.c0 : (w == 1 ? x.c1 : (w == 2 ? x.c2 : 0u));
+    const uint32_t hi = w == 0 ? x.c1 : (w == 1 ? x.c2 : 0u);
+    return __funnelshift_r(lo, hi, sh) & 0xFFFFu;
+}
+__device__ __forceinline__ uint32_t spread16(uint32_t x) {  // bit i -> bit 2i
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+// dword K (0..4) of the from-square's slice: targets j' in [16K, 16K+16) of the 80-entry "to without from" order
+template <int K>
+__device__ __forceinline__ uint32_t slice_word(Stream81 tn, Stream81 tp, int from) {
+    const int r = from - 16 * K;                                  // how many of this window's entries lie below `from`
+    const uint32_t m = r <= 0 ? 0u : (r >= 16 ? 0xFFFFu : ((1u << r) - 1u));
+    const uint32_t n = (stream_ext16<16 * K>(tn) & m) | (stream_ext16<16 * K + 1>(tn) & ~m & 0xFFFFu);
+    const uint32_t q = (stream_ext16<16 * K>(tp) & m) | (stream_ext16<16 * K + 1>(tp) & ~m & 0xFFFFu);
+    return spread16(n) | (spread16(q) << 1);
+}
+
 #ifdef KSH_STAMPS
 #define GEN_STAMP(k)                                                              \
     do {                                                                          \
@@ -239,8 +280,6 @@ __device__ __forceinline__ int ksh_gen(KshBlockLds &L, KshWaveLds &W, int lane, 
     const int np = n_lo + __popcll(occ_hi);
     if (p0 != 0) W.plist[__popcll(occ_lo & ((1ull << lane) - 1ull))] = (uint8_t)lane;
     if (p1 != 0) W.plist[n_lo + __popcll(occ_hi & ((1ull << lane) - 1ull))] = (uint8_t)(64 + lane);
-    W.pin_dir[lane] = 0xFF;
-    if (lane < 32) W.pin_dir[64 + lane] = 0xFF;
     wave_lds_sync();
 
     GEN_STAMP(11);  // occupancy ballots + compaction
@@ -273,8 +312,7 @@ __device__ __forceinline__ int ksh_gen(KshBlockLds &L, KshWaveLds &W, int lane, 
         }
     }
     GEN_STAMP(12);  // attack sets
-    // enemy attack map (OR over enemy pieces) and files holding an own unpromoted pawn (nifu)
-    const BB3 eatt = BB3{wave_or(foe ? att.w0 : 0u), wave_or(foe ? att.w1 : 0u), wave_or(foe ? att.w2 : 0u)};
+    // files holding an own unpromoted pawn (nifu)
     const uint32_t nifu = wave_or((mine && type == 0) ? (1u << (sq - 9 * sq_row(sq))) : 0u);
     // checkers: enemy pieces attacking the king square
     const unsigned long long chk = __ballot(foe && ksq >= 0 && bb_test(att, ksq));
@@ -282,32 +320,44 @@ __device__ __forceinline__ int ksh_gen(KshBlockLds &L, KshWaveLds &W, int lane, 
     const int csq = __shfl(sq, chk ? (__ffsll((long long)chk) - 1) : 0);
     in_check = (ksq < 0) || ncheck > 0;  // king missing => "in check" (shogi_rules_logic.py:42-55)
     const bool opp_in_check = __ballot(mine && eksq >= 0 && bb_test(att, eksq)) != 0ull;
+    // king flight squares attacked by the enemy (sliders see through the lifted king): one ballot per candidate
+    // square instead of OR-reducing whole attack maps across the wave
+    BB3 katt = bb_zero();
+    if (ksq >= 0) {
+        const int kr = sq_row(ksq), kc = ksq - 9 * kr;
+#pragma unroll
+        for (int d = 0; d < 8; d++) {                   // same direction order as the ray tables
+            const int r = kr + ((d == 0 || d == 4 || d == 6) ? -1 : ((d == 1 || d == 5 || d == 7) ? 1 : 0));
+            const int c = kc + ((d == 2 || d == 4 || d == 7) ? -1 : ((d == 3 || d == 5 || d == 6) ? 1 : 0));
+            const bool on = r >= 0 && r < 9 && c >= 0 && c < 9;
+            const int t = on ? r * 9 + c : 0;
+            const bool hit = __ballot(foe && on && bb_test(att, t)) != 0ull;
+            if (hit) katt = bb_or(katt, bb_sq(t));
+        }
+    }
 
-    GEN_STAMP(13);  // reductions + checkers
-    // ---- lane = ray from the king: pins
-    if (lane < 8 && ksq >= 0) {
-        const int d = lane;
-        const bool pos = (d & 1) != 0;
-        BB3 M = lds_bb(L.tab.ray, d, ksq);
-        BB3 B = bb_and(M, occ);
-        const int n1 = bb_nearest(B, pos);
-        if (n1 >= 0) {
-            const int q1 = brd[n1];
-            if ((q1 >= 15) == (me == 1)) {  // nearest piece is ours: is there an enemy slider right behind it?
-                const int n2 = bb_nearest(bb_andn(B, bb_sq(n1)), pos);
+    GEN_STAMP(13);  // nifu + checkers + king flights
+    // ---- lane = own piece: is it pinned?  (aligned with the king, nothing in between, enemy slider right behind)
+    bool pinned = false;
+    int pin_d = 0;
+    if (mine && ksq >= 0 && sq != ksq) {
+        const int d = sq_dir(ksq, sq);
+        if (d >= 0) {
+            const BB3 between = bb_and(lds_bb(L.tab.ray, d, ksq), lds_bb(L.tab.ray, d ^ 1, sq));
+            if (!bb_any(bb_and(between, occ))) {
+                const int n2 = bb_nearest(bb_and(lds_bb(L.tab.ray, d, sq), occ), (d & 1) != 0);
                 if (n2 >= 0) {
                     const int q2 = brd[n2];
                     if ((q2 >= 15) != (me == 1)) {
                         const int t2 = q2 - 1 - (q2 >= 15 ? 14 : 0);
-                        const bool slides = (d < 4) ? (t2 == 6 || t2 == 13 || (t2 == 1 && d == me))
-                                                    : (t2 == 5 || t2 == 12);
-                        if (slides) W.pin_dir[n1] = (uint8_t)d;
+                        // rook-likes pin along ranks/files, bishop-likes along diagonals, a lance only from in front
+                        const bool slides = (d < 4) ? (t2 == 6 || t2 == 13 || (t2 == 1 && d == me)) : (t2 == 5 || t2 == 12);
+                        if (slides) { pinned = true; pin_d = d; }
                     }
                 }
             }
         }
     }
-    wave_lds_sync();
 
     // squares a non-king move must land on while in check; squares a drop may use
     BB3 block = BB3{KSH_M27, KSH_M27, KSH_M27};
@@ -330,11 +380,10 @@ __device__ __forceinline__ int ksh_gen(KshBlockLds &L, KshWaveLds &W, int lane, 
     if (mine && ksq >= 0) {
         BB3 T = bb_andn(att, own);
         if (sq == ksq) {
-            T = bb_andn(T, eatt);
+            T = bb_andn(T, katt);
         } else {
             T = bb_and(T, block);
-            const int pd = W.pin_dir[sq];
-            if (pd != 0xFF) T = bb_and(T, lds_bb(L.tab.ray, pd, ksq));
+            if (pinned) T = bb_and(T, lds_bb(L.tab.ray, pin_d, ksq));
         }
         // promotion rules (shogi_rules_logic.py:382-421)
         const bool promotable = type <= 3 || type == 5 || type == 6;
@@ -349,22 +398,14 @@ __device__ __forceinline__ int ksh_gen(KshBlockLds &L, KshWaveLds &W, int lane, 
         const BB3 Tp = promotable ? (from_zone ? T : bb_and(T, zone)) : bb_zero();
         const BB3 Tn = bb_andn(T, must);
         cnt = __popc(Tp.w0) + __popc(Tp.w1) + __popc(Tp.w2) + __popc(Tn.w0) + __popc(Tn.w1) + __popc(Tn.w2);
-        if (emit) {
-#pragma unroll
-            for (int w = 0; w < 3; w++) {
-                uint32_t bits = w == 0 ? T.w0 : (w == 1 ? T.w1 : T.w2);
-                const uint32_t bn = w == 0 ? Tn.w0 : (w == 1 ? Tn.w1 : Tn.w2);
-                const uint32_t bp = w == 0 ? Tp.w0 : (w == 1 ? Tp.w1 : Tp.w2);
-                while (bits) {
-                    const int b = __ffs((int)bits) - 1;
-                    bits &= bits - 1u;
-                    const int to = 27 * w + b;
-                    // utils/utils.py:208-241 in closed form
-                    const int base = (sq * 80 + to - (to > sq ? 1 : 0)) * 2;
-                    if ((bn >> b) & 1u) atomicOr(&W.maskbits[base >> 5], 1u << (base & 31));
-                    if ((bp >> b) & 1u) atomicOr(&W.maskbits[(base + 1) >> 5], 1u << ((base + 1) & 31));
-                }
-            }
+        if (emit && cnt != 0) {
+            const Stream81 sn = bb_stream(Tn), sp = bb_stream(Tp);
+            uint32_t *out = &W.maskbits[5 * sq];             // this from-square's private 160-bit slice
+            out[0] = slice_word<0>(sn, sp, sq);
+            out[1] = slice_word<1>(sn, sp, sq);
+            out[2] = slice_word<2>(sn, sp, sq);
+            out[3] = slice_word<3>(sn, sp, sq);
+            out[4] = slice_word<4>(sn, sp, sq);
         }
     }
 
@@ -444,30 +485,6 @@ __device__ __forceinline__ int ksh_gen_full(KshBlockLds &L, KshWaveLds &W, int l
     return n;
 }
 
-// 64-bit key of (board, hands, side to move): the reference compares exact tuples
-// (shogi/shogi_game.py:347-372); a 2x32-bit mixed XOR key stands in for it (collision odds ~2^-64 per pair).
-__device__ __forceinline__ unsigned long long ksh_hash(KshWaveLds &W, int lane) {
-    const uint8_t *brd = ST8(W);
-    uint32_t ha = 0, hb = 0;
-#pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-        const int s = pass * 64 + lane;
-        if (s < 81 && brd[s] != 0) {
-            const uint32_t key = (uint32_t)(s * 32 + brd[s]);
-            ha ^= fmix32(key * 0x9E3779B1u + 0x7F4A7C15u);
-            hb ^= fmix32((key ^ 0x5bd1e995u) * 0x2545F491u + 0x1B873593u);
-        }
-    }
-    if (lane < 14 && brd[S_HAND + lane] != 0) {
-        const uint32_t key = 0x10000u + (uint32_t)lane * 256u + brd[S_HAND + lane];
-        ha ^= fmix32(key * 0x9E3779B1u + 0x7F4A7C15u);
-        hb ^= fmix32((key ^ 0x5bd1e995u) * 0x2545F491u + 0x1B873593u);
-    }
-    unsigned long long h = ((unsigned long long)wave_xor(hb) << 32) | wave_xor(ha);
-    if (brd[S_SIDE]) h ^= 0xA5A5F00D5EED1234ull;
-    return h;
-}
-
 // Observation of the state in W.st32 (shogi/shogi_game_io.py:434-539), POV of the side to move, written with
 // coalesced 16-byte stores.  Planes 0-27 are one-hot piece planes: they are first collected as a 2 268-bit
 // set in LDS (one LDS atomic per piece) and expanded 4 bits -> 4 floats per lane; planes 28-45 are constant
@@ -478,7 +495,7 @@ __device__ __forceinline__ float ksh_obs_elem(const KshWaveLds &W, int f) {
     if (f < KSH_BOARD_F) return ((W.obsbits[f >> 5] >> (f & 31)) & 1u) ? 1.0f : 0.0f;
     return W.metav[(unsigned)(f - KSH_BOARD_F) / 81u];
 }
-__device__ __forceinline__ void ksh_write_obs(const KshBlockLds &L, KshWaveLds &W, const KshStepArgs &a, int g, int lane) {
+__device__ __forceinline__ void ksh_write_obs(KshWaveLds &W, const KshStepArgs &a, int g, int lane, int mf_idx, float mf_hint) {
     const uint8_t *st8 = ST8(W);
     const int side = st8[S_SIDE];
     for (int i = lane; i < 80; i += 64) W.obsbits[i] = 0;
@@ -498,14 +515,15 @@ __device__ __forceinline__ void ksh_write_obs(const KshBlockLds &L, KshWaveLds &
         // planes 28-34 own hand, 35-41 opponent hand; count/18.0 in double, stored as float32 (:513-527)
         const int cidx = lane < 7 ? side : 1 - side;
         const int cnt = st8[S_HAND + 7 * cidx + (lane < 7 ? lane : lane - 7)];
-        W.metav[lane] = cnt < 32 ? L.tab.hand_lut[cnt] : (float)((double)cnt / 18.0);
+        W.metav[lane] = (float)((double)cnt / 18.0);
     } else if (lane == 14) {
         W.metav[14] = side == 0 ? 1.0f : 0.0f;
     } else if (lane == 15) {
         // move_count / max_moves in double, stored as float32 (:535-536): host-built table, division only past its end
         const int mcount = st8[S_MC] | (st8[S_MC + 1] << 8);
-        W.metav[15] = mcount == W.move_idx ? W.move_frac
-                                           : (a.max_moves > 0 ? (float)((double)mcount / (double)a.max_moves) : 0.0f);
+        // the state record carries the value for its NEXT move count; anything else is divided here
+        W.metav[15] = mcount == mf_idx ? mf_hint
+                                       : (a.max_moves > 0 ? (float)((double)mcount / (double)a.max_moves) : 0.0f);
     } else if (lane < 20) {
         W.metav[lane] = 0.0f;
     }
@@ -527,7 +545,7 @@ __device__ __forceinline__ void ksh_write_obs(const KshBlockLds &L, KshWaveLds &
             v.y = (x & 2u) ? 0x3F800000u : 0u;
             v.z = (x & 4u) ? 0x3F800000u : 0u;
             v.w = (x & 8u) ? 0x3F800000u : 0u;
-            *reinterpret_cast<uint4 *>(orow + f) = v;
+            ksh_store16(orow + f, v);
         }
     }
 #pragma unroll
@@ -544,7 +562,7 @@ __device__ __forceinline__ void ksh_write_obs(const KshBlockLds &L, KshWaveLds &
             } else {                                // the one chunk straddling plane 27 / 28
                 v = make_float4(ksh_obs_elem(W, f), ksh_obs_elem(W, f + 1), ksh_obs_elem(W, f + 2), ksh_obs_elem(W, f + 3));
             }
-            *reinterpret_cast<float4 *>(orow + f) = v;
+            ksh_store16(orow + f, uint4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)});
         }
     }
     if (lane == 0) {
@@ -553,6 +571,10 @@ __device__ __forceinline__ void ksh_write_obs(const KshBlockLds &L, KshWaveLds &
     }
 }
 
+// Order of one step, chosen around two hardware facts: (1) the kernel is HBM-write bound, so the first
+// observation store must leave as early as possible -- everything it does not need (table staging, move
+// generation) comes after it; (2) on gfx9 loads and stores share one in-order vmcnt, so every global LOAD of
+// a wave (state, action, history, tables) is issued AND consumed before its first observation store.
 extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(KshStepArgs a) {
     __shared__ KshBlockLds L;
 #ifdef KSH_STAMPS
@@ -562,208 +584,225 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // scalar: makes g and every address built from it uniform
     const int g = blockIdx.x * KSH_WPB + wv;
     const bool live = g < a.n_games;
-    // issue this game's global loads first so that their latency hides behind the table staging
+    KshWaveLds &W = L.wave[wv];
+    uint8_t *st8 = ST8(W);
+
+    // ---- all loads up front: this game's state + action, then the block's share of the attack tables
     uint32_t st_word = 0;
     long long act = -1;
     if (live) {
         if (lane < 32) st_word = reinterpret_cast<const uint32_t *>(a.state + (size_t)g * 128)[lane];
         if (a.mode == 2) act = a.actions[g];
     }
-    // stage the attack tables in LDS (24.8 KB, shared by the block's waves): all loads in flight, then the stores
-    {
-        constexpr int NV = (int)(sizeof(KshTables) / 16);   // 1548 uint4 = 6 * 256 + 12
-        constexpr int NT = 64 * KSH_WPB;
-        static_assert(NV >= 6 * NT && NV < 7 * NT, "staging below is written for 6 full rounds + a remainder");
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.tables) + threadIdx.x;
-        uint4 *dst = reinterpret_cast<uint4 *>(&L.tab) + threadIdx.x;
-        const uint4 t0 = src[0], t1 = src[NT], t2 = src[2 * NT], t3 = src[3 * NT], t4 = src[4 * NT], t5 = src[5 * NT];
-        uint4 t6 = {0u, 0u, 0u, 0u};
-        const bool rem = (int)threadIdx.x < NV - 6 * NT;
-        if (rem) t6 = src[6 * NT];
-        dst[0] = t0; dst[NT] = t1; dst[2 * NT] = t2; dst[3 * NT] = t3; dst[4 * NT] = t4; dst[5 * NT] = t5;
-        if (rem) dst[6 * NT] = t6;
-    }
-    __syncthreads();
-    if (!live) return;  // wave-uniform
-    KshWaveLds &W = L.wave[wv];
-    uint8_t *st8 = ST8(W);
-#ifdef KSH_STAMPS
-    if (lane == 0 && a.stamps) a.stamps[(size_t)g * 32 + 0] = t_entry;
-#endif
-    KSH_STAMP(1);  // tables staged
+    constexpr int NV = (int)(sizeof(KshTables) / 16);   // uint4 count: 6 full rounds of 256 threads + a remainder
+    constexpr int NT = 64 * KSH_WPB;
+    static_assert(NV >= 6 * NT && NV < 7 * NT, "staging below is written for 6 full rounds + a remainder");
+    const uint4 *tsrc = reinterpret_cast<const uint4 *>(a.tables) + threadIdx.x;
+    const uint4 t0 = tsrc[0], t1 = tsrc[NT], t2 = tsrc[2 * NT], t3 = tsrc[3 * NT], t4 = tsrc[4 * NT], t5 = tsrc[5 * NT];
+    uint4 t6 = {0u, 0u, 0u, 0u};
+    const bool trem = (int)threadIdx.x < NV - 6 * NT;
+    if (trem) t6 = tsrc[6 * NT];
 
-    // ---- state record into LDS, clear the legal bit-set
-    if (lane < 32) W.st32[lane] = st_word;
-    for (int i = lane; i < KSH_MASKW; i += 64) W.maskbits[i] = 0;
-    wave_lds_sync();
-
-    // history prefetch (step mode): the entry this move will append is hidx = move_count - base
-    const int hidx = (int)(st8[S_MC] | (st8[S_MC + 1] << 8)) - (int)(st8[S_HBASE] | (st8[S_HBASE + 1] << 8));
-    const bool hist_ok = a.mode == 2 && hidx >= 0 && hidx < a.hist_cap;
-    unsigned long long *hrow = a.hist + (size_t)g * (size_t)a.hist_cap;
-    unsigned long long h0 = 0, h1 = 0, h2 = 0, h3 = 0;
-    if (hist_ok) {
-        if (lane < hidx) h0 = hrow[lane];
-        if (64 + lane < hidx) h1 = hrow[64 + lane];
-        if (128 + lane < hidx) h2 = hrow[128 + lane];
-        if (192 + lane < hidx) h3 = hrow[192 + lane];
-    }
-    {
-        // move-count plane value of the state this launch will encode (after the move in step mode)
-        const int mc_enc = (int)(st8[S_MC] | (st8[S_MC + 1] << 8)) + ((a.mode == 2 && st8[S_OVER] == 0) ? 1 : 0);
-        float mf;
-        if (mc_enc < a.hist_cap) mf = a.move_lut[mc_enc];
-        else mf = a.max_moves > 0 ? (float)((double)mc_enc / (double)a.max_moves) : 0.0f;
-        if (lane == 0) { W.move_frac = mf; W.move_idx = mc_enc; }
-    }
-    KSH_STAMP(2);  // state loaded
     int out_done = 0, out_reason = 0, out_winner = -1, n_out = 0;
-    bool obs_written = false;
+    bool obs_written = false, need_gen = true, moved = false;
     float out_reward = 0.0f;
-    bool need_gen = true;
+    int me = 0, mover = 0, mc = 0, rep = 1, mf_idx = -1;
+    float mf_hint = 0.0f;
 
-    if (a.mode == 1) {
-        const bool rs = a.reset_mask == nullptr || a.reset_mask[g] != 0;
-        if (rs) {
-            if (lane < 32) W.st32[lane] = reinterpret_cast<const uint32_t *>(L.tab.init_state)[lane];
-            wave_lds_sync();
+    if (live) {
+        // ---- state record into LDS, clear the legal bit-set
+        if (lane < 32) W.st32[lane] = st_word;
+        for (int i = lane; i < KSH_MASKW; i += 64) W.maskbits[i] = 0;
+        wave_lds_sync();
+#ifdef KSH_STAMPS
+        if (lane == 0 && a.stamps) a.stamps[(size_t)g * 32 + 0] = t_entry;
+#endif
+        KSH_STAMP(1);  // state in LDS
+
+        // ---- history prefetch (step mode): this move appends entry hidx = move_count - base; the first 512
+        // earlier entries go to registers now (max_moves = 500 never needs more)
+        const int hidx = (int)(st8[S_MC] | (st8[S_MC + 1] << 8)) - (int)(st8[S_HBASE] | (st8[S_HBASE + 1] << 8));
+        const bool hist_ok = a.mode == 2 && hidx >= 0 && hidx < a.hist_cap;
+        unsigned long long *hrow = a.hist + (size_t)g * (size_t)a.hist_cap;
+        unsigned long long hv[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            hv[k] = 0;
+            if (hist_ok && 64 * k + lane < hidx) hv[k] = hrow[64 * k + lane];
+        }
+
+        if (a.mode == 1) {
+            const bool rs = a.reset_mask == nullptr || a.reset_mask[g] != 0;
+            if (rs) {
+                if (lane < 32) W.st32[lane] = reinterpret_cast<const uint32_t *>(a.tables->init_state)[lane];
+                wave_lds_sync();
+            }
+        }
+        me = st8[S_SIDE];
+        if (a.mode == 2) {
+            mover = me;
+            const bool over = st8[S_OVER] != 0;
+            if (over) {
+                // stepping a finished game (no auto-reset): nothing moves (shogi_game.py:589-593)
+                const int w = (int)st8[S_WINNER] - 1;
+                out_done = 1;
+                out_reason = st8[S_REASON];
+                out_winner = w;
+                out_reward = (w == 1 - me) ? 1.0f : (w < 0 ? 0.0f : -1.0f);
+            } else {
+                bool ok = act >= 0 && act < KSH_A;
+                if (ok && a.prev_mask != nullptr) ok = a.prev_mask[(size_t)g * KSH_A + (size_t)act] != 0;
+                int from = -1, to = 0, aux = 0, pcf = 0, pct = 0;
+                if (ok) {
+                    const int ai = (int)act;
+                    if (ai >= 12960) {
+                        const int k = ai - 12960;
+                        to = k / 7;
+                        aux = k - 7 * to;
+                        ok = st8[to] == 0 && st8[S_HAND + 7 * mover + aux] != 0;
+                    } else {
+                        const int pair = ai >> 1;
+                        aux = ai & 1;
+                        from = pair / 80;
+                        const int j = pair - 80 * from;
+                        to = j + (j >= from ? 1 : 0);
+                        pcf = st8[from];
+                        pct = st8[to];
+                        ok = pcf != 0 && ((pcf >= 15) == (mover == 1)) && !(pct != 0 && ((pct >= 15) == (mover == 1)));
+                        const int tf = pcf - 1 - (pcf >= 15 ? 14 : 0);
+                        if (aux && !(tf <= 3 || tf == 5 || tf == 6)) ok = false;
+                    }
+                }
+                if (!ok) {
+                    // the reference raises ValueError and StepManager resets the episode (step_manager.py:303-348)
+                    out_done = 1;
+                    out_reason = 5;
+                    if (a.auto_reset) {
+                        if (lane < 32) W.st32[lane] = reinterpret_cast<const uint32_t *>(a.tables->init_state)[lane];
+                        wave_lds_sync();
+                        me = 0;
+                    }
+                } else {
+                    // ---- apply the move (shogi_move_execution.py:24-156) and update the position key; every lane
+                    // computes the same values, lane 0 writes the record
+                    unsigned long long h = *reinterpret_cast<const unsigned long long *>(st8 + S_HASH) ^ KSH_SIDE_KEY;
+                    mf_hint = *reinterpret_cast<const float *>(st8 + S_NFRAC);
+                    mc = (st8[S_MC] | (st8[S_MC + 1] << 8)) + 1;
+                    mf_idx = mc;
+                    int hslot = -1, hold = 0, hnew = 0, newpc;
+                    if (from < 0) {
+                        newpc = 1 + aux + 14 * mover;
+                        hslot = 7 * mover + aux;
+                        hold = st8[S_HAND + hslot];
+                        hnew = hold - 1;
+                        h ^= ksh_mix_sq(to, newpc);
+                    } else {
+                        newpc = pcf;
+                        if (aux) {
+                            const int tf = pcf - 1 - 14 * mover;
+                            newpc = 1 + 14 * mover + (tf <= 3 ? tf + 8 : tf + 7);
+                        }
+                        h ^= ksh_mix_sq(from, pcf) ^ ksh_mix_sq(to, newpc);
+                        if (pct != 0) {
+                            h ^= ksh_mix_sq(to, pct);
+                            int tt = pct - 1 - (pct >= 15 ? 14 : 0);
+                            if (tt >= 8) tt = (tt >= 12) ? tt - 7 : tt - 8;  // +P..+S -> P..S, +B,+R -> B,R
+                            if (tt < 7) {                                    // a captured king is not kept
+                                hslot = 7 * mover + tt;
+                                hold = st8[S_HAND + hslot];
+                                hnew = hold + 1;
+                            }
+                        }
+                    }
+                    if (hslot >= 0) {
+                        if (hold > 0) h ^= ksh_mix_hand(hslot, hold);
+                        if (hnew > 0) h ^= ksh_mix_hand(hslot, hnew);
+                    }
+                    wave_lds_sync();
+                    if (lane == 0) {
+                        st8[to] = (uint8_t)newpc;
+                        if (from >= 0) st8[from] = 0;
+                        if (hslot >= 0) st8[S_HAND + hslot] = (uint8_t)hnew;
+                        st8[S_MC] = (uint8_t)(mc & 0xFF);
+                        st8[S_MC + 1] = (uint8_t)(mc >> 8);
+                        st8[S_SIDE] = (uint8_t)(1 - mover);
+                        *reinterpret_cast<unsigned long long *>(st8 + S_HASH) = h;
+                    }
+                    wave_lds_sync();
+                    me = 1 - mover;
+                    moved = true;
+                    KSH_STAMP(3);  // move applied + key updated
+                    // ---- append the key to the game's history and count its earlier occurrences
+                    if (hist_ok) {
+                        if (lane == 0) hrow[hidx] = h;
+                        int matches = 0;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) matches += __popcll(__ballot(64 * k + lane < hidx && hv[k] == h));
+                        for (int base = 512; base < hidx; base += 64) {  // bounded: hidx < hist_cap; only for max_moves > 512
+                            const int i = base + lane;
+                            const bool m = (i < hidx) && hrow[i] == h;
+                            matches += __popcll(__ballot(m));
+                        }
+                        rep += matches;
+                    }
+                    KSH_STAMP(4);  // history scanned
+                    // ---- observation of the post-move state: issued NOW so the stores drain while the tables are
+                    // staged and the move generator runs; rewritten below in the rare case the game ends and is reset
+                    ksh_write_obs(W, a, g, lane, mf_idx, mf_hint);
+                    obs_written = true;
+                    KSH_STAMP(5);  // obs stores issued
+                }
+            }
         }
     }
 
-    int me = st8[S_SIDE];
-    if (a.mode == 2) {
-        const int mover = me;
-        const bool over = st8[S_OVER] != 0;
-        if (over) {
-            // stepping a finished game (no auto-reset): nothing moves (shogi_game.py:589-593)
-            const int w = (int)st8[S_WINNER] - 1;
-            out_done = 1;
-            out_reason = st8[S_REASON];
-            out_winner = w;
-            out_reward = (w == 1 - me) ? 1.0f : (w < 0 ? 0.0f : -1.0f);
-        } else {
-            bool ok = act >= 0 && act < KSH_A;
-            if (ok && a.prev_mask != nullptr) ok = a.prev_mask[(size_t)g * KSH_A + (size_t)act] != 0;
-            int from = -1, to = 0, aux = 0;
-            if (ok) {
-                const int ai = (int)act;
-                if (ai >= 12960) {
-                    const int k = ai - 12960;
-                    to = k / 7;
-                    aux = k - 7 * to;
-                    ok = st8[to] == 0 && st8[S_HAND + 7 * mover + aux] != 0;
-                } else {
-                    const int pair = ai >> 1;
-                    aux = ai & 1;
-                    from = pair / 80;
-                    const int j = pair - 80 * from;
-                    to = j + (j >= from ? 1 : 0);
-                    const int pcf = st8[from], pct = st8[to];
-                    ok = pcf != 0 && ((pcf >= 15) == (mover == 1)) && !(pct != 0 && ((pct >= 15) == (mover == 1)));
-                    const int tf = pcf - 1 - (pcf >= 15 ? 14 : 0);
-                    if (aux && !(tf <= 3 || tf == 5 || tf == 6)) ok = false;
-                }
-            }
-            if (!ok) {
-                // the reference raises ValueError and StepManager resets the episode (step_manager.py:303-348)
-                out_done = 1;
-                out_reason = 5;
-                if (a.auto_reset) {
-                    if (lane < 32) W.st32[lane] = reinterpret_cast<const uint32_t *>(L.tab.init_state)[lane];
-                    wave_lds_sync();
-                    me = 0;
-                }
-            } else {
-                // ---- apply the move (shogi_move_execution.py:24-156); every lane computes, lane 0 writes
-                wave_lds_sync();
-                if (lane == 0) {
-                    if (from < 0) {
-                        st8[to] = (uint8_t)(1 + aux + 14 * mover);
-                        st8[S_HAND + 7 * mover + aux] -= 1;
-                    } else {
-                        const int pcf = st8[from], pct = st8[to];
-                        if (pct != 0) {
-                            int tt = pct - 1 - (pct >= 15 ? 14 : 0);
-                            if (tt >= 8) tt = (tt >= 12) ? tt - 7 : tt - 8;  // +P..+S -> P..S, +B,+R -> B,R
-                            if (tt < 7) st8[S_HAND + 7 * mover + tt] += 1;   // a captured king is not kept
-                        }
-                        int np_ = pcf;
-                        if (aux) {
-                            const int tf = pcf - 1 - 14 * mover;
-                            np_ = 1 + 14 * mover + (tf <= 3 ? tf + 8 : tf + 7);
-                        }
-                        st8[to] = (uint8_t)np_;
-                        st8[from] = 0;
-                    }
-                    const int mc = (st8[S_MC] | (st8[S_MC + 1] << 8)) + 1;
-                    st8[S_MC] = (uint8_t)(mc & 0xFF);
-                    st8[S_MC + 1] = (uint8_t)(mc >> 8);
-                    st8[S_SIDE] = (uint8_t)(1 - mover);
-                }
-                wave_lds_sync();
-                me = 1 - mover;
-                const int mc = st8[S_MC] | (st8[S_MC + 1] << 8);
-                KSH_STAMP(3);  // move applied
-                // ---- position key of the post-move state, appended to the game's history.  All global LOADS of
-                // this wave happen before its first observation store: on gfx9 loads and stores share one in-order
-                // vmcnt, so a load waited on after the stores would stall until the stores have drained.
-                const unsigned long long h = ksh_hash(W, lane);
-                int rep = 1;
-                if (hist_ok) {
-                    if (lane == 0) hrow[hidx] = h;
-                    int matches = __popcll(__ballot(lane < hidx && h0 == h)) + __popcll(__ballot(64 + lane < hidx && h1 == h)) +
-                                  __popcll(__ballot(128 + lane < hidx && h2 == h)) + __popcll(__ballot(192 + lane < hidx && h3 == h));
-                    for (int base = 256; base < hidx; base += 64) {  // bounded: hidx < hist_cap
-                        const int i = base + lane;
-                        const bool m = (i < hidx) && hrow[i] == h;
-                        matches += __popcll(__ballot(m));
-                    }
-                    rep += matches;
-                }
-                KSH_STAMP(4);  // hashed + history scanned
-                // ---- observation of the post-move state: issued NOW so the stores drain while the move
-                // generator runs; rewritten below in the rare case the game ends and is reset
-                ksh_write_obs(L, W, a, g, lane);
-                obs_written = true;
-                KSH_STAMP(5);  // obs stores issued
-                // ---- legal moves of the side now to move (+ nested uchi-fu-zume reply search)
-                bool chk;
+    // ---- attack tables into LDS (24.9 KB, shared by the block's waves); their loads were issued at the top
+    {
+        uint4 *tdst = reinterpret_cast<uint4 *>(&L.tab) + threadIdx.x;
+        tdst[0] = t0; tdst[NT] = t1; tdst[2 * NT] = t2; tdst[3 * NT] = t3; tdst[4 * NT] = t4; tdst[5 * NT] = t5;
+        if (trem) tdst[6 * NT] = t6;
+    }
+    __syncthreads();
+    if (!live) return;  // wave-uniform
+    KSH_STAMP(2);  // tables staged
+
+    if (moved) {
+        // ---- legal moves of the side now to move (+ nested uchi-fu-zume reply search)
+        bool chk;
 #ifdef KSH_STAMPS
-                int n = ksh_gen_full(L, W, lane, me, chk, a.stamps ? a.stamps + (size_t)g * 32 + 16 : nullptr);
+        int n = ksh_gen_full(L, W, lane, me, chk, a.stamps ? a.stamps + (size_t)g * 32 + 16 : nullptr);
 #else
-                int n = ksh_gen_full(L, W, lane, me, chk);
+        int n = ksh_gen_full(L, W, lane, me, chk);
 #endif
-                KSH_STAMP(6);  // movegen done
-                need_gen = false;
-                n_out = n;
-                // ---- termination (shogi_game.py:408-450): no moves -> max moves -> sennichite
-                if (n == 0) {
-                    out_done = 1;
-                    if (chk) { out_reason = 1; out_winner = mover; out_reward = 1.0f; }
-                    else { out_reason = 2; }
-                } else if (mc >= a.max_moves) {
-                    out_done = 1;
-                    out_reason = 3;
-                } else if (rep >= 4) {
-                    out_done = 1;
-                    out_reason = 4;
-                }
-                if (out_done) {
-                    if (a.auto_reset) {
-                        if (lane < 32) W.st32[lane] = reinterpret_cast<const uint32_t *>(L.tab.init_state)[lane];
-                        for (int i = lane; i < KSH_MASKW; i += 64) W.maskbits[i] = 0;
-                        wave_lds_sync();
-                        me = 0;
-                        need_gen = true;
-                        obs_written = false;   // the observation must show the reset position
-                    } else if (lane == 0) {
-                        st8[S_OVER] = 1;
-                        st8[S_REASON] = (uint8_t)out_reason;
-                        st8[S_WINNER] = (uint8_t)(out_winner + 1);
-                    }
-                    wave_lds_sync();
-                }
+        KSH_STAMP(6);  // movegen done
+        need_gen = false;
+        n_out = n;
+        // ---- termination (shogi_game.py:408-450): no moves -> max moves -> sennichite
+        if (n == 0) {
+            out_done = 1;
+            if (chk) { out_reason = 1; out_winner = mover; out_reward = 1.0f; }
+            else { out_reason = 2; }
+        } else if (mc >= a.max_moves) {
+            out_done = 1;
+            out_reason = 3;
+        } else if (rep >= 4) {
+            out_done = 1;
+            out_reason = 4;
+        }
+        if (out_done) {
+            if (a.auto_reset) {
+                if (lane < 32) W.st32[lane] = reinterpret_cast<const uint32_t *>(L.tab.init_state)[lane];
+                for (int i = lane; i < KSH_MASKW; i += 64) W.maskbits[i] = 0;
+                wave_lds_sync();
+                me = 0;
+                need_gen = true;
+                obs_written = false;   // the observation must show the reset position
+            } else if (lane == 0) {
+                st8[S_OVER] = 1;
+                st8[S_REASON] = (uint8_t)out_reason;
+                st8[S_WINNER] = (uint8_t)(out_winner + 1);
             }
+            wave_lds_sync();
         }
     }
 
@@ -774,22 +813,11 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
     }
     wave_lds_sync();
     KSH_STAMP(7);  // termination / reset-regen done
-    if (lane == 0) a.n_legal[g] = n_out;
-
-    // ---- write back the state and the per-game scalars
-    if (lane < 32) reinterpret_cast<uint32_t *>(a.state + (size_t)g * 128)[lane] = W.st32[lane];
-    if (a.mode == 2 && lane == 0) {
-        a.reward[g] = out_reward;
-        a.done[g] = (uint8_t)out_done;
-        a.reason[g] = (uint8_t)out_reason;
-        a.winner[g] = (signed char)out_winner;
-    }
 
     // ---- observation, unless it was already issued right after the move
-    KSH_STAMP(8);
-    if (!obs_written) ksh_write_obs(L, W, a, g, lane);
+    if (!obs_written) ksh_write_obs(W, a, g, lane, mf_idx, mf_hint);
+    KSH_STAMP(9);
 
-    KSH_STAMP(9);  // obs stores issued
     // ---- legal mask: expand the bit-set to one byte per action, 16-byte aligned stores
     {
         uint8_t *mrow = a.mask + (size_t)g * KSH_A;
@@ -810,7 +838,7 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
                 v.y = __umul24((x >> 4) & 0xFu, 0x204081u) & 0x01010101u;
                 v.z = __umul24((x >> 8) & 0xFu, 0x204081u) & 0x01010101u;
                 v.w = __umul24((x >> 12) & 0xFu, 0x204081u) & 0x01010101u;
-                *reinterpret_cast<uint4 *>(mrow + b0) = v;
+                ksh_store16(mrow + b0, v);
             }
         }
         const int ntail = KSH_A - tail0;
@@ -820,4 +848,19 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
         }
     }
     KSH_STAMP(10);  // mask stores issued
+
+    // ---- with every output store in flight: finish the record for the next step and write it back
+    if (lane == 0) {
+        const int mcn = (st8[S_MC] | (st8[S_MC + 1] << 8)) + 1;
+        *reinterpret_cast<float *>(st8 + S_NFRAC) = a.max_moves > 0 ? (float)((double)mcn / (double)a.max_moves) : 0.0f;
+        a.n_legal[g] = n_out;
+        if (a.mode == 2) {
+            a.reward[g] = out_reward;
+            a.done[g] = (uint8_t)out_done;
+            a.reason[g] = (uint8_t)out_reason;
+            a.winner[g] = (signed char)out_winner;
+        }
+    }
+    wave_lds_sync();
+    if (lane < 32) reinterpret_cast<uint32_t *>(a.state + (size_t)g * 128)[lane] = W.st32[lane];
 }

@@ -36,7 +36,6 @@ struct KshEnv {
     uint8_t *state;
     unsigned long long *hist;
     KshTables *tables;
-    float *move_lut;
 };
 
 extern "C" {
@@ -55,9 +54,9 @@ int ksh_env_create(int device, int n_games, int max_moves, void **handle) {
     e->state = nullptr;
     e->hist = nullptr;
     e->tables = nullptr;
-    e->move_lut = nullptr;
     KshTables *t = new KshTables();
     ksh_build_tables(t);
+    ksh_finish_record(t->init_state, max_moves);   // position key + next move-count plane value
     hipError_t err = hipMalloc(&e->state, (size_t)n_games * 128);
     if (err == hipSuccess) err = hipMalloc(&e->hist, (size_t)n_games * e->hist_cap * sizeof(unsigned long long));
     if (err == hipSuccess) err = hipMalloc(&e->tables, sizeof(KshTables));
@@ -67,19 +66,12 @@ int ksh_env_create(int device, int n_games, int max_moves, void **handle) {
         for (int g = 0; g < n_games; g++) memcpy(&init[(size_t)g * 128], t->init_state, 128);
         err = hipMemcpy(e->state, init.data(), init.size(), hipMemcpyHostToDevice);
     }
-    if (err == hipSuccess) err = hipMalloc(&e->move_lut, (size_t)e->hist_cap * sizeof(float));
-    if (err == hipSuccess) {
-        std::vector<float> lut((size_t)e->hist_cap);
-        for (int i = 0; i < e->hist_cap; i++) lut[i] = (float)((double)i / (double)max_moves);  // shogi_game_io.py:535-536
-        err = hipMemcpy(e->move_lut, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice);
-    }
     if (err == hipSuccess) err = hipMemset(e->hist, 0, (size_t)n_games * e->hist_cap * sizeof(unsigned long long));
     delete t;
     if (err != hipSuccess) {
         if (e->state) (void)hipFree(e->state);
         if (e->hist) (void)hipFree(e->hist);
         if (e->tables) (void)hipFree(e->tables);
-        if (e->move_lut) (void)hipFree(e->move_lut);
         delete e;
         return fail_hip(err, "ksh_env_create");
     }
@@ -93,7 +85,6 @@ int ksh_env_destroy(void *handle) {
     (void)hipFree(e->state);
     (void)hipFree(e->hist);
     (void)hipFree(e->tables);
-    (void)hipFree(e->move_lut);
     delete e;
     return KSH_OK;
 }
@@ -113,7 +104,6 @@ static int launch_env(KshEnv *e, int mode, const int64_t *actions, const uint8_t
     a.state = e->state;
     a.hist = e->hist;
     a.tables = e->tables;
-    a.move_lut = e->move_lut;
     a.actions = reinterpret_cast<const long long *>(actions);
     a.prev_mask = prev_mask;
     a.reset_mask = reset_mask;
@@ -173,6 +163,7 @@ int ksh_env_set_state(void *handle, int game, const uint8_t *state128, void *str
     if (rec[S_SIDE] > 1) { g_err = "ksh_env_set_state: side to move must be 0 or 1"; return KSH_E_STATE; }
     rec[S_HBASE] = rec[S_MC];  // the position history starts empty at this ply (from_sfen: shogi_game.py:320-321)
     rec[S_HBASE + 1] = rec[S_MC + 1];
+    ksh_finish_record(rec, e->max_moves);
     HIP_TRY(hipMemcpyAsync(e->state + (size_t)game * 128, rec, 128, hipMemcpyHostToDevice, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return KSH_OK;

@@ -230,6 +230,7 @@ __device__ __forceinline__ uint32_t ksh_philox(uint32_t c0, uint32_t c1, uint32_
 // mask row (all loads in flight), and only for non-zero bytes gathers the logit -- a real position has ~50
 // legal actions out of 13 527, so the logits of illegal actions are never read.
 #define KSH_SAMPLE_WPB 4
+#define KSH_SAMPLE_CAP 1024
 
 struct KshSampleAcc {
     float m, s, key, zbest;
@@ -264,13 +265,27 @@ ksh_masked_sample_kernel(const T *__restrict__ logits, const uint8_t *__restrict
     const uint32_t s0 = (uint32_t)step, s1 = (uint32_t)(step >> 32);
     const bool det = deterministic != 0;
     KshSampleAcc A = {-INFINITY, 0.0f, -INFINITY, 0.0f, -1};
+    // Legal ids are first collected in a per-wave LDS list and then dealt round-robin to the lanes: drop ids
+    // of one square are 7 consecutive actions, so without this a single lane would gather up to 16 logits one
+    // after the other.  Ids beyond the list capacity (dense masks) are visited directly by the lane that found them.
+    __shared__ unsigned short s_list[KSH_SAMPLE_WPB][KSH_SAMPLE_CAP];
+    __shared__ unsigned int s_cnt[KSH_SAMPLE_WPB];
+    const int wv = (int)(threadIdx.x >> 6);
+    if (lane == 0) s_cnt[wv] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    auto push = [&](int j) {
+        const unsigned slot = atomicAdd(&s_cnt[wv], 1u);
+        if (slot < KSH_SAMPLE_CAP) s_list[wv][slot] = (unsigned short)j;
+        else ksh_sample_visit<T>(A, row, j, b, det, s0, s1, k0, k1);
+    };
 
     const size_t addr = reinterpret_cast<size_t>(mrow);
     const int head = (int)((16 - (addr & 15)) & 15);
     const int nfull = (KSH_PA - head) >> 4;               // 844 or 845 aligned chunks
     const int tail0 = head + 16 * nfull;
-    if (lane < head && mrow[lane]) ksh_sample_visit<T>(A, row, lane, b, det, s0, s1, k0, k1);
-    if (lane < KSH_PA - tail0 && mrow[tail0 + lane]) ksh_sample_visit<T>(A, row, tail0 + lane, b, det, s0, s1, k0, k1);
+    if (lane < head && mrow[lane]) push(lane);
+    if (lane < KSH_PA - tail0 && mrow[tail0 + lane]) push(tail0 + lane);
 #pragma unroll
     for (int half = 0; half < 2; half++) {                 // 2 x 7 x 64 = 896 >= 845 chunks, 7 loads in flight per lane
         uint4 ch[7];
@@ -291,11 +306,18 @@ ksh_masked_sample_kernel(const T *__restrict__ logits, const uint8_t *__restrict
                     while (v) {                             // visit the non-zero bytes of this dword
                         const int byte = (__ffs((int)v) - 1) >> 3;
                         v &= ~(0xFFu << (8 * byte));
-                        ksh_sample_visit<T>(A, row, j0 + 4 * q + byte, b, det, s0, s1, k0, k1);
+                        push(j0 + 4 * q + byte);
                     }
                 }
             }
         }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+        const unsigned total = s_cnt[wv];
+        const int n = (int)(total < KSH_SAMPLE_CAP ? total : KSH_SAMPLE_CAP);
+        for (int e = lane; e < n; e += 64) ksh_sample_visit<T>(A, row, (int)s_list[wv][e], b, det, s0, s1, k0, k1);
     }
     // wave reductions (xor butterfly): soft-max statistics and the arg-max with its logit
 #pragma unroll

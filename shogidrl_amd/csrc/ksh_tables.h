@@ -17,9 +17,50 @@ struct KshTables {
     uint32_t ray[8][81][4];    // [dir][sq] -> {w0,w1,w2,0}: squares from sq (exclusive) to the edge
     uint32_t step[11][81][4];  // [class][sq] -> {w0,w1,w2,0}
     uint8_t init_state[128];   // packed initial position (shogi_game.py:79-130)
-    float hand_lut[32];        // (float)((double)count / 18.0), the hand-plane value (shogi_game_io.py:513-527)
+    uint8_t pad[16];
 };
 static_assert(sizeof(KshTables) % 16 == 0, "tables are copied to LDS as uint4");
+
+// ---- position key (sennichite).  The reference compares exact (board, hands, side) tuples
+// (shogi/shogi_game.py:347-372); here a 64-bit XOR of mixed per-item keys stands in for it.  The kernel
+// maintains it incrementally (a move touches at most five items); the host computes it from scratch for the
+// initial position and for ksh_env_set_state.  State record: bytes 104-111 hash, 112-115 float
+// (move_count+1)/max_moves (the move-count plane value of the NEXT position, so no step needs a division or
+// a dependent table load before it can start writing the observation).
+#define KSH_S_HASH 104
+#define KSH_S_NFRAC 112
+#define KSH_SIDE_KEY 0xA5A5F00D5EED1234ull
+
+__host__ __device__ static inline uint32_t ksh_fmix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ static inline unsigned long long ksh_mix_key(uint32_t key) {
+    const uint32_t a = ksh_fmix32(key * 0x9E3779B1u + 0x7F4A7C15u);
+    const uint32_t b = ksh_fmix32((key ^ 0x5bd1e995u) * 0x2545F491u + 0x1B873593u);
+    return ((unsigned long long)b << 32) | a;
+}
+// piece code pc (1..28) standing on square sq
+__host__ __device__ static inline unsigned long long ksh_mix_sq(int sq, int pc) { return ksh_mix_key((uint32_t)(sq * 32 + pc)); }
+// `cnt` (> 0) pieces of hand slot (0..13 = black P..R, white P..R)
+__host__ __device__ static inline unsigned long long ksh_mix_hand(int slot, int cnt) {
+    return ksh_mix_key(0x10000u + (uint32_t)slot * 256u + (uint32_t)cnt);
+}
+static inline unsigned long long ksh_full_hash(const uint8_t *rec) {
+    unsigned long long h = 0;
+    for (int s = 0; s < 81; s++) if (rec[s]) h ^= ksh_mix_sq(s, rec[s]);
+    for (int k = 0; k < 14; k++) if (rec[81 + k]) h ^= ksh_mix_hand(k, rec[81 + k]);
+    if (rec[95]) h ^= KSH_SIDE_KEY;
+    return h;
+}
+// fills the derived fields (hash, next move fraction) of a packed state record
+static inline void ksh_finish_record(uint8_t *rec, int max_moves) {
+    const unsigned long long h = ksh_full_hash(rec);
+    memcpy(rec + KSH_S_HASH, &h, 8);
+    const int mc = rec[96] | (rec[97] << 8);
+    const float f = max_moves > 0 ? (float)((double)(mc + 1) / (double)max_moves) : 0.0f;
+    memcpy(rec + KSH_S_NFRAC, &f, 4);
+}
 
 static inline void ksh_bb_set(uint32_t *w, int sq) { w[sq / 27] |= 1u << (sq % 27); }
 
@@ -68,5 +109,4 @@ static inline void ksh_build_tables(KshTables *t) {
     b[1 * 9 + 7] = 1 + 5 + 14;
     b[7 * 9 + 1] = 1 + 5;
     b[7 * 9 + 7] = 1 + 6;
-    for (int i = 0; i < 32; i++) t->hand_lut[i] = (float)((double)i / 18.0);
 }

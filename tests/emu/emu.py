@@ -12,8 +12,11 @@ A = 13527
 def _lib():
     subprocess.check_call(["make", "-C", _DIR, "-s"])
     L = C.CDLL(os.path.join(_DIR, "libksh_emu.so"))
-    L.emu_env_launch.argtypes = [C.c_void_p] * 14 + [C.c_int] * 5
-    L.emu_build_tables.argtypes = [C.c_void_p]
+    L.emu_env_launch.argtypes = [C.c_void_p] * 13 + [C.c_int] * 5
+    L.emu_build_tables.argtypes = [C.c_void_p, C.c_int]
+    L.emu_finish_record.argtypes = [C.c_void_p, C.c_int]
+    L.emu_full_hash.argtypes = [C.c_void_p]
+    L.emu_full_hash.restype = C.c_uint64
     return L
 
 
@@ -23,8 +26,7 @@ class EmuEnv:
         self.n, self.max_moves = n, max_moves
         self.cap = max_moves + 1
         self.tables = np.zeros(self.L.emu_tables_size(), np.uint8)
-        self.L.emu_build_tables(self.tables.ctypes.data)
-        self.move_lut = (np.arange(self.cap, dtype=np.float64) / float(max_moves)).astype(np.float32)
+        self.L.emu_build_tables(self.tables.ctypes.data, max_moves)
         self.state = np.zeros((n, 128), np.uint8)
         self.hist = np.zeros((n, self.cap), np.uint64)
         self.obs = np.zeros((n, 46, 9, 9), np.float32)
@@ -39,7 +41,7 @@ class EmuEnv:
         p = lambda x: None if x is None else x.ctypes.data
         self.obs[:] = -7.0          # poison: every byte must be rewritten
         self.mask[:] = 0xCC
-        self.L.emu_env_launch(p(self.state), p(self.hist), p(self.tables), p(self.move_lut), p(actions), p(prev_mask), p(reset_mask),
+        self.L.emu_env_launch(p(self.state), p(self.hist), p(self.tables), p(actions), p(prev_mask), p(reset_mask),
                               p(self.obs), p(self.mask), p(self.n_legal), p(self.reward), p(self.done),
                               p(self.reason), p(self.winner), self.n, self.max_moves, self.cap, mode, auto_reset)
 
@@ -63,7 +65,16 @@ class EmuEnv:
         rec = np.array(rec128, np.uint8).copy()
         mc = int(rec[96]) | (int(rec[97]) << 8)
         rec[102], rec[103] = mc & 0xFF, mc >> 8      # history starts empty at this ply
+        rec[104:] = 0
+        self.L.emu_finish_record(rec.ctypes.data, self.max_moves)
         self.state[g] = rec
+
+    def check_hashes(self):
+        """the incrementally maintained position key of every game equals the key computed from scratch"""
+        for g in range(self.n):
+            rec = np.ascontiguousarray(self.state[g])
+            stored = int(rec[104:112].view(np.uint64)[0])
+            assert stored == self.L.emu_full_hash(rec.ctypes.data), g
 
 
 # ------------------------------------------------------------------ learner-side kernels

@@ -114,3 +114,5 @@ struct bf16 {
 // value of the first lane of the wave (all lanes are active wherever the kernels use it)
 #define __builtin_amdgcn_readfirstlane(x) (__shfl((int)(x), 0))
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))

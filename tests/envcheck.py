@@ -171,4 +171,6 @@ def check_random_vs_oracle(make_env, n_games, n_steps, seed, max_moves=500, drop
                 bad = np.nonzero((x != y).reshape(n_games, -1).any(axis=1))[0]
                 raise AssertionError("step %d: %s differs for games %s" % (k, name, bad[:8].tolist()))
         ndone += int(done.sum())
+        if hasattr(env, "check_hashes"):
+            env.check_hashes()
     return ndone

@@ -29,8 +29,9 @@ for t in range(80):
     env.step(a, validate=False)
 st = torch.zeros(N, 32, dtype=torch.int64, device="cuda:0")
 L.ksh_debug_set_stamps(st.data_ptr())
-names = ["entry", "tables", "state", "applied", "hashed", "hist", "movegen", "term/regen", "obs tbl", "obs st", "mask st"]
-acc = np.zeros((10,), np.float64)
+order = [0, 1, 3, 4, 5, 2, 6, 7, 9, 10]
+names = ["entry", "state in LDS", "applied+key", "history", "obs stores", "tables+barrier", "movegen", "term/regen", "late obs", "mask stores"]
+acc = np.zeros((9,), np.float64)
 gacc = np.zeros((7,), np.float64)
 nested = 0.0
 span = 0.0
@@ -42,18 +43,18 @@ for t in range(reps):
     torch.cuda.synchronize()
     s = st.cpu().numpy().astype(np.float64)
     ok = (s[:, 3] > 0)
-    d = np.diff(s[ok][:, :11], axis=1)
+    d = np.diff(s[ok][:, order], axis=1)
     acc += np.median(d, axis=0)
     gs = s[ok]
     # inside the first move generation: stamps 16+11..16+15, end of main gen at 16+10, flag nested at 16+9
-    seq = np.stack([gs[:, 5], gs[:, 27], gs[:, 28], gs[:, 29], gs[:, 30], gs[:, 31], gs[:, 26], gs[:, 6]], axis=1)
+    seq = np.stack([gs[:, 2], gs[:, 27], gs[:, 28], gs[:, 29], gs[:, 30], gs[:, 31], gs[:, 26], gs[:, 6]], axis=1)
     gacc += np.median(np.diff(seq, axis=1), axis=0)
     nested += gs[:, 25].mean()
     span += (s[:, 10].max() - s[:, 0].min())
 L.ksh_debug_set_stamps(None)
 print("N=%d median per-wave phase durations (s_memtime ticks = 100 MHz? or shader clk), avg over %d steps" % (N, reps))
-for i in range(10):
-    print("  %-12s -> %-12s %9.1f" % (names[i], names[i + 1], acc[i] / reps))
+for i in range(9):
+    print("  %-14s -> %-14s %9.1f" % (names[i], names[i + 1], acc[i] / reps))
 print("  sum %.1f ; kernel span (first entry -> last end) %.1f" % (acc.sum() / reps, span / reps))
 gn = ["obs issued->ballots+compact", "attack sets", "reductions+checkers", "pins+block", "board emit", "drops+count (main gen end)", "ufz nested + rest"]
 for i in range(7):
