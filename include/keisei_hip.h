@@ -74,6 +74,13 @@ int ksh_env_reset(void *handle, const uint8_t *reset_mask /*dev [N] or NULL*/, f
 /* Re-encode the current state of every game without changing it (observation + legal mask). */
 int ksh_env_observe(void *handle, float *obs /*dev*/, uint8_t *legal_mask /*dev*/, int32_t *n_legal /*dev*/, void *stream);
 
+/* Like ksh_env_observe, and additionally evaluates the termination of every (not yet finished) game's current
+ * position the way ShogiGame.from_sfen does after loading one (shogi/shogi_game.py:331-343): no legal move ->
+ * Tsumi (winner = the side NOT to move) or stalemate; otherwise move_count >= max_moves -> "Max moves reached".
+ * Finished games are marked in their state record; done / reason / winner receive the verdicts. */
+int ksh_env_evaluate_termination(void *handle, float *obs /*dev*/, uint8_t *legal_mask /*dev*/, int32_t *n_legal /*dev*/,
+                                 uint8_t *done /*dev*/, uint8_t *reason /*dev*/, int8_t *winner /*dev*/, void *stream);
+
 /* One env step for every game: apply actions[g], detect termination, optionally auto-reset finished
  * games, then write the NEXT observation / legal mask (of the reset position for finished games when
  * auto_reset != 0, exactly as StepManager discards the terminal observation).

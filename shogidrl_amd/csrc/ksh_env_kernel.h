@@ -57,7 +57,7 @@ struct KshStepArgs {
     int n_games;
     int max_moves;
     int hist_cap;
-    int mode;                  // 0 observe, 1 reset (masked), 2 step
+    int mode;                  // 0 observe, 1 reset (masked), 2 step, 3 observe + evaluate termination (from_sfen)
     int auto_reset;
     unsigned long long *stamps; // diagnostic build only (-DKSH_STAMPS): [N][16] s_memtime values
 };
@@ -810,6 +810,22 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
         bool chk;
         int n = ksh_gen_full(L, W, lane, me, chk);
         n_out = n;
+        if (a.mode == 3 && st8[S_OVER] != 0) {          // already marked finished: report the stored verdict
+            out_done = 1;
+            out_reason = st8[S_REASON];
+            out_winner = (int)st8[S_WINNER] - 1;
+        } else if (a.mode == 3) {
+            // termination of a freshly loaded position, as ShogiGame.from_sfen evaluates it (shogi_game.py:331-343):
+            // no legal move -> Tsumi (winner = the side NOT to move) / stalemate; else move_count >= max_moves
+            const int mcount = st8[S_MC] | (st8[S_MC + 1] << 8);
+            if (n == 0) { out_done = 1; out_reason = chk ? 1 : 2; out_winner = chk ? 1 - me : -1; }
+            else if (mcount >= a.max_moves) { out_done = 1; out_reason = 3; }
+            if (out_done && lane == 0) {
+                st8[S_OVER] = 1;
+                st8[S_REASON] = (uint8_t)out_reason;
+                st8[S_WINNER] = (uint8_t)(out_winner + 1);
+            }
+        }
     }
     wave_lds_sync();
     KSH_STAMP(7);  // termination / reset-regen done
@@ -854,8 +870,8 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
         const int mcn = (st8[S_MC] | (st8[S_MC + 1] << 8)) + 1;
         *reinterpret_cast<float *>(st8 + S_NFRAC) = a.max_moves > 0 ? (float)((double)mcn / (double)a.max_moves) : 0.0f;
         a.n_legal[g] = n_out;
-        if (a.mode == 2) {
-            a.reward[g] = out_reward;
+        if (a.mode == 2 || (a.mode == 3 && a.done != nullptr)) {
+            if (a.reward != nullptr) a.reward[g] = out_reward;
             a.done[g] = (uint8_t)out_done;
             a.reason[g] = (uint8_t)out_reason;
             a.winner[g] = (signed char)out_winner;

@@ -139,6 +139,14 @@ int ksh_env_observe(void *handle, float *obs, uint8_t *legal_mask, int32_t *n_le
                       nullptr, nullptr, 0, stream);
 }
 
+int ksh_env_evaluate_termination(void *handle, float *obs, uint8_t *legal_mask, int32_t *n_legal, uint8_t *done,
+                                 uint8_t *reason, int8_t *winner, void *stream) {
+    if (!handle) return fail_arg("ksh_env_evaluate_termination: null handle");
+    if (!done || !reason || !winner) return fail_arg("ksh_env_evaluate_termination: null output");
+    return launch_env((KshEnv *)handle, 3, nullptr, nullptr, nullptr, obs, legal_mask, n_legal, nullptr, done, reason, winner,
+                      0, stream);
+}
+
 int ksh_env_step(void *handle, const int64_t *actions, const uint8_t *prev_mask, float *next_obs, uint8_t *next_mask,
                  int32_t *n_legal, float *reward, uint8_t *done, uint8_t *reason, int8_t *winner, int auto_reset,
                  void *stream) {

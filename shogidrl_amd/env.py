@@ -96,6 +96,14 @@ class VecShogiEnv:
                                       _stream()), "ksh_env_observe")
         return self.obs, self.legal_mask
 
+    def evaluate_termination(self):
+        """observe() + mark games whose CURRENT position is already terminal, as ShogiGame.from_sfen does
+        (shogi_game.py:331-343). Returns (obs, legal_mask); done / reason / winner hold the verdicts."""
+        check(self._L.ksh_env_evaluate_termination(self._h, self.obs.data_ptr(), self.legal_mask.data_ptr(),
+                                                   self.n_legal.data_ptr(), self.done.data_ptr(), self.reason.data_ptr(),
+                                                   self.winner.data_ptr(), _stream()), "ksh_env_evaluate_termination")
+        return self.obs, self.legal_mask
+
     def step(self, actions, validate=True, out_obs=None, out_mask=None, prev_mask=None):
         """actions: int64 [N] on the device.  Returns (obs, reward, terminated, truncated, info).
 

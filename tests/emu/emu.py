@@ -54,6 +54,11 @@ class EmuEnv:
         self._launch(0)
         return self.obs.copy(), self.mask.copy(), self.n_legal.copy()
 
+    def evaluate_termination(self):
+        self._launch(3)
+        return (self.obs.copy(), self.mask.copy(), self.n_legal.copy(), self.done.copy(), self.reason.copy(),
+                self.winner.copy())
+
     def step(self, actions, auto_reset=True, check_prev=True):
         a = np.ascontiguousarray(actions, np.int64)
         pm = self.mask.copy() if check_prev else None

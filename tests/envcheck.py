@@ -87,7 +87,13 @@ def check_positions(make_env):
     for s, rec in enumerate(recs):
         g = ko.Game(max_moves=rec["max_moves"], sfen=rec["sfen"])
         games.append(g)
-        env.set_state(s, g.export_state())
+        st = g.export_state()
+        st[98:101] = 0          # drop the oracle's verdict: the device must evaluate the loaded position itself
+        env.set_state(s, st)
+    # from_sfen semantics: the loaded position's termination is evaluated on the device (shogi_game.py:331-343)
+    obs, mask, nl, done, reason, winner = env.evaluate_termination()
+    for s, rec in enumerate(recs):
+        assert (bool(done[s]), int(reason[s]), int(winner[s])) == (rec["game_over"], rec["reason"], rec["winner"]), rec["sfen"]
     obs, mask, nl = env.observe()
     for s, rec in enumerate(recs):
         assert mask_ids(mask[s]) == rec["legal"], rec["sfen"]

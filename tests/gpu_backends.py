@@ -32,6 +32,13 @@ class GpuEnv:
         self.env.observe()
         return self._out()
 
+    def evaluate_termination(self):
+        e = self.env
+        e.evaluate_termination()
+        obs, mask, nl = self._out()
+        return (obs, mask, nl, e.done.cpu().numpy().astype(np.uint8), e.reason.cpu().numpy().copy(),
+                e.winner.cpu().numpy().copy())
+
     def step(self, actions, auto_reset=True, check_prev=True):
         e = self.env
         e.auto_reset = bool(auto_reset)

@@ -134,3 +134,41 @@ def test_reference_style_single_game_calls():
     assert lp <= 0 and isinstance(v, float) and isinstance(agent.get_value(obs[0].cpu().numpy()), float)
     move2, idx2, _, _ = agent.select_action(obs[0].cpu().numpy(), mask[0], is_training=False)
     assert bool(mask[0, idx2])
+
+
+def test_single_game_facade_matches_positions_fixture():
+    """ShogiGame facade (from_sfen / get_legal_moves / make_move / to_sfen_string) against the golden positions."""
+    import json
+    from shogidrl_amd.game import ShogiGame, parse_sfen, state_to_sfen
+    from shogidrl_amd.mapper import PolicyOutputMapper
+    from tests.envcheck import obs_crc
+    mp = PolicyOutputMapper()
+    recs = json.load(open(os.path.join(G, "positions.json")))
+    n = 0
+    for rec in recs[:70]:
+        if not rec["valid"]:
+            if not rec.get("error", "").startswith("unmappable"):
+                with pytest.raises(ValueError):
+                    parse_sfen(rec["sfen"])
+            continue
+        g = ShogiGame.from_sfen(rec["sfen"])
+        assert g.game_over == rec["game_over"], rec["sfen"]
+        if rec["game_over"]:
+            assert REASONS[g.termination_reason] == rec["reason"] and (g.winner if g.winner is not None else -1) == rec["winner"]
+        assert sorted(mp.shogi_move_to_policy_index(m) for m in g.get_legal_moves()) == rec["legal"], rec["sfen"]
+        assert obs_crc(g.get_observation()) == rec["obs_crc"]
+        assert g.current_player == rec["side"] and g.move_count == rec["move_count"]
+        assert state_to_sfen(parse_sfen(rec["sfen"])).split()[0] == rec["sfen"].split()[0]
+        for ply in rec.get("playout", [])[:6]:
+            obs, r, d, info = g.make_move(mp.policy_index_to_shogi_move(ply["a"]))
+            assert (r, d, REASONS[info["reason"]]) == (ply["r"], ply["done"], ply["reason"])
+            assert obs_crc(obs) == ply["obs_crc"]
+            n += 1
+    g = ShogiGame()
+    assert len(g.get_legal_moves()) == 30 and g.to_sfen_string() == "lnsgkgsnl/1r5b1/ppppppppp/9/9/9/PPPPPPPPP/1B5R1/LNSGKGSNL b - 1"
+    with pytest.raises(ValueError):
+        g.make_move((0, 0, 5, 5, False))            # not a legal move: the reference raises ValueError too
+    assert n > 100
+
+
+REASONS = {None: 0, "Game ongoing": 0, "Tsumi": 1, "stalemate": 2, "Max moves reached": 3, "Sennichite": 4}
