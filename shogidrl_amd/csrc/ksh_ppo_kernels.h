@@ -286,7 +286,6 @@ ksh_masked_sample_kernel(const T *__restrict__ logits, const uint8_t *__restrict
     const int tail0 = head + 16 * nfull;
     if (lane < head && mrow[lane]) push(lane);
     if (lane < KSH_PA - tail0 && mrow[tail0 + lane]) push(tail0 + lane);
-#pragma unroll
     for (int half = 0; half < 2; half++) {                 // 2 x 7 x 64 = 896 >= 845 chunks, 7 loads in flight per lane
         uint4 ch[7];
 #pragma unroll
