@@ -172,3 +172,14 @@ def test_single_game_facade_matches_positions_fixture():
 
 
 REASONS = {None: 0, "Game ongoing": 0, "Tsumi": 1, "stalemate": 2, "Max moves reached": 3, "Sennichite": 4}
+
+
+def test_batched_evaluation_games_finish_and_agree_with_oracle():
+    from oracle import ko
+    from shogidrl_amd.evaluation import UniformRandomPolicy, play_games
+    res = play_games(UniformRandomPolicy(1), UniformRandomPolicy(2), num_games=96, max_moves_per_game=120,
+                     deterministic=False)
+    assert res.games == 96 and res.black_wins + res.white_wins + res.draws == 96
+    assert sum(res.reasons.values()) == 96 and set(res.reasons) <= {"Tsumi", "stalemate", "Max moves reached", "Sennichite"}
+    assert 20 <= res.avg_game_length <= 120
+    assert res.reasons.get("Tsumi", 0) == res.black_wins + res.white_wins     # only Tsumi produces a winner
