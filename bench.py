@@ -137,7 +137,7 @@ def main():
 
     torch.manual_seed(42)                        # same init on every rank (then kept in sync by the all-reduce)
     model = ResTowerActorCritic(46, 13527, args.depth, args.width, 0.25)
-    cfg = PPOConfig(ppo_epochs=args.epochs, minibatch_size=args.minibatch, mixed_precision=True, channels_last=False,
+    cfg = PPOConfig(ppo_epochs=args.epochs, minibatch_size=args.minibatch, mixed_precision=True, channels_last=True,
                     seed=42 + rank)
     agent = VecPPOAgent(model, cfg, dev)
     env = VecShogiEnv(args.games, 500, device=dev)

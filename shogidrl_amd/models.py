@@ -25,6 +25,18 @@ class TinyActorCritic(nn.Module):
         return self.policy_head(h), self.value_head(h).squeeze(-1)
 
 
+class _BN(nn.BatchNorm2d):
+    """nn.BatchNorm2d (same parameters / buffers / state-dict keys) evaluated by ATen's native batch-norm kernels
+    instead of MIOpen's: on MI355X with channels_last bf16 activations that is the faster pairing with MIOpen's
+    NHWC implicit-GEMM convolutions (no layout transposes, tower fwd+bwd 83 -> 71 ms at batch 4096)."""
+
+    def forward(self, x):
+        if x.is_cuda:
+            with torch.backends.cudnn.flags(enabled=False):
+                return super().forward(x)
+        return super().forward(x)
+
+
 class _SE(nn.Module):
     def __init__(self, channels, ratio):
         super().__init__()
@@ -41,9 +53,9 @@ class _Block(nn.Module):
     def __init__(self, channels, se_ratio):
         super().__init__()
         self.conv1 = nn.Conv2d(channels, channels, 3, padding=1)
-        self.bn1 = nn.BatchNorm2d(channels)
+        self.bn1 = _BN(channels)
         self.conv2 = nn.Conv2d(channels, channels, 3, padding=1)
-        self.bn2 = nn.BatchNorm2d(channels)
+        self.bn2 = _BN(channels)
         self.se = _SE(channels, se_ratio) if se_ratio else None
 
     def forward(self, x):
@@ -61,11 +73,11 @@ class ResTowerActorCritic(nn.Module):
     def __init__(self, input_channels=46, num_actions_total=NUM_ACTIONS, tower_depth=9, tower_width=256, se_ratio=0.25):
         super().__init__()
         self.stem = nn.Conv2d(input_channels, tower_width, 3, padding=1)
-        self.bn_stem = nn.BatchNorm2d(tower_width)
+        self.bn_stem = _BN(tower_width)
         self.res_blocks = nn.Sequential(*[_Block(tower_width, se_ratio) for _ in range(tower_depth)])
-        self.policy_head = nn.Sequential(nn.Conv2d(tower_width, 2, 1), nn.BatchNorm2d(2), nn.ReLU(), nn.Flatten(),
+        self.policy_head = nn.Sequential(nn.Conv2d(tower_width, 2, 1), _BN(2), nn.ReLU(), nn.Flatten(),
                                          nn.Linear(2 * 81, num_actions_total))
-        self.value_head = nn.Sequential(nn.Conv2d(tower_width, 2, 1), nn.BatchNorm2d(2), nn.ReLU(), nn.Flatten(),
+        self.value_head = nn.Sequential(nn.Conv2d(tower_width, 2, 1), _BN(2), nn.ReLU(), nn.Flatten(),
                                         nn.Linear(2 * 81, 1))
 
     def trunk(self, x):

@@ -5,13 +5,29 @@ from shogidrl_amd.models import ResTowerActorCritic
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 variants = sys.argv[2].split(",") if len(sys.argv) > 2 else ["nchw_bf16", "nhwc_bf16", "nchw_fp32"]
 dev = "cuda:0"
+import torch.nn.functional as F
+class NativeBN(torch.nn.BatchNorm2d):
+    def forward(self, x):
+        with torch.backends.cudnn.flags(enabled=False):
+            return super().forward(x)
+def swap_bn(mod):
+    for name, ch in mod.named_children():
+        if isinstance(ch, torch.nn.BatchNorm2d):
+            nb = NativeBN(ch.num_features).to(ch.weight.device)
+            nb.load_state_dict(ch.state_dict())
+            setattr(mod, name, nb)
+        else:
+            swap_bn(ch)
 for v in variants:
     torch.manual_seed(0)
+    torch.backends.cudnn.benchmark = "bench" in v
     m = ResTowerActorCritic().to(dev)
     cl = v.startswith("nhwc")
     if cl:
         m = m.to(memory_format=torch.channels_last)
-    amp = v.endswith("bf16")
+    amp = "bf16" in v
+    if "nativebn" in v:
+        swap_bn(m)
     x = torch.randn(B, 46, 9, 9, device=dev)
     if cl:
         x = x.contiguous(memory_format=torch.channels_last)
