@@ -1,4 +1,6 @@
 """Scratch micro-benchmark of the env kernel (random legal self-play). Superseded by bench.py."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sys
 import time
 

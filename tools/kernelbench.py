@@ -1,4 +1,6 @@
 """Scratch micro-benchmark of the learner-side kernels on realistic inputs (masks from real self-play)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sys
 import torch
 from shogidrl_amd import ops

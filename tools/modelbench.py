@@ -1,4 +1,6 @@
 """Scratch: throughput of the PyTorch tower (fwd+bwd) under a few layouts. Not part of the product."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sys, time, os
 import torch
 from shogidrl_amd.models import ResTowerActorCritic

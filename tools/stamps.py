@@ -1,5 +1,7 @@
 """Scratch diagnostic: builds a -DKSH_STAMPS copy of the library and prints the per-phase shader-clock
 breakdown of the env kernel (guide section 7, 'In-kernel stamps'). Never used by the product."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
 import os
 import subprocess
@@ -8,7 +10,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 so = os.path.join(ROOT, "gpurun_out", "libkeisei_hip_stamps.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-DKSH_STAMPS",
