@@ -30,9 +30,17 @@ def lib():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise KeiseiHipError(
-            "shogidrl_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        # not a fallback: build the HIP library itself (hipcc --offload-arch=gfx950) when a checkout has no binary yet
+        try:
+            from . import build as _build
+            if os.environ.get("SHOGIDRL_AMD_LIB"):
+                raise RuntimeError("SHOGIDRL_AMD_LIB points at a missing file")
+            _build.build(verbose=False)
+        except Exception as e:
+            raise KeiseiHipError(
+                "shogidrl_amd: %s is missing and could not be built (%s). Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback." % (LIB_PATH, e))
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double
     L.ksh_last_error.restype = C.c_char_p

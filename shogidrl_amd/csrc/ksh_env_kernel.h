@@ -528,12 +528,13 @@ __device__ __forceinline__ void ksh_write_obs(KshWaveLds &W, const KshStepArgs &
         W.metav[lane] = 0.0f;
     }
     wave_lds_sync();
-    // row g covers global floats [g*3726, (g+1)*3726); 3726 = 2 (mod 4): even rows start on a 16-byte
-    // boundary and end with half a chunk, odd rows start with the other half.
+    // Row g starts at a 4-byte aligned address (rows are 14 904 B apart, so even when the tensor itself is 16-byte
+    // aligned every other row is not): `head` floats are written singly up to the first 16-byte boundary, then
+    // aligned 16-byte chunks, then the 0-3 remaining floats.
     float *orow = a.obs + (size_t)g * KSH_OBSF;
-    const int head = (g & 1) ? 2 : 0;               // floats before the first fully aligned chunk
-    const int nfull = (KSH_OBSF - head) >> 2;       // 931 in both cases
-    const int nboard = (KSH_BOARD_F - head) >> 2;   // chunks lying entirely inside planes 0-27 (567 / 566)
+    const int head = (int)(((16 - (reinterpret_cast<size_t>(orow) & 15)) & 15) >> 2);
+    const int nfull = (KSH_OBSF - head) >> 2;       // 930 or 931 aligned chunks
+    const int nboard = (KSH_BOARD_F - head) >> 2;   // chunks lying entirely inside planes 0-27
 #pragma unroll
     for (int it = 0; it < 9; it++) {                // 9 * 64 >= 567: constant trip count so the LDS reads batch up
         const int c = lane + 64 * it;
@@ -565,10 +566,9 @@ __device__ __forceinline__ void ksh_write_obs(KshWaveLds &W, const KshStepArgs &
             ksh_store16(orow + f, uint4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)});
         }
     }
-    if (lane == 0) {
-        const int f = head ? 0 : 4 * nfull;         // the half chunk: floats 0,1 of an odd row / 3724,3725 of an even row
-        *reinterpret_cast<float2 *>(orow + f) = make_float2(ksh_obs_elem(W, f), ksh_obs_elem(W, f + 1));
-    }
+    if (lane < head) orow[lane] = ksh_obs_elem(W, lane);
+    const int tail0 = head + 4 * nfull;
+    if (lane < KSH_OBSF - tail0) orow[tail0 + lane] = ksh_obs_elem(W, tail0 + lane);
 }
 
 // Order of one step, chosen around two hardware facts: (1) the kernel is HBM-write bound, so the first

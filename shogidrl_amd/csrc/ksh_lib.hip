@@ -98,7 +98,7 @@ static int launch_env(KshEnv *e, int mode, const int64_t *actions, const uint8_t
                       float *obs, uint8_t *mask, int32_t *n_legal, float *reward, uint8_t *done, uint8_t *reason,
                       int8_t *winner, int auto_reset, void *stream) {
     if (!obs || !mask || !n_legal) return fail_arg("env: obs / mask / n_legal must not be null");
-    if ((reinterpret_cast<size_t>(obs) & 15) != 0) return fail_arg("env: obs must be 16-byte aligned");
+    if ((reinterpret_cast<size_t>(obs) & 3) != 0) return fail_arg("env: obs must be 4-byte aligned");
     if (mode == 2 && (!actions || !reward || !done || !reason || !winner)) return fail_arg("env step: null output");
     KshStepArgs a;
     a.state = e->state;

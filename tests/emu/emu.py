@@ -21,7 +21,7 @@ def _lib():
 
 
 class EmuEnv:
-    def __init__(self, n, max_moves=500):
+    def __init__(self, n, max_moves=500, obs_offset=0):
         self.L = _lib()
         self.n, self.max_moves = n, max_moves
         self.cap = max_moves + 1
@@ -29,7 +29,9 @@ class EmuEnv:
         self.L.emu_build_tables(self.tables.ctypes.data, max_moves)
         self.state = np.zeros((n, 128), np.uint8)
         self.hist = np.zeros((n, self.cap), np.uint64)
-        self.obs = np.zeros((n, 46, 9, 9), np.float32)
+        # obs_offset (in floats) shifts the output buffer to exercise every 16-byte alignment phase of the rows
+        self._obs_store = np.zeros(n * 46 * 81 + 8, np.float32)
+        self.obs = self._obs_store[obs_offset:obs_offset + n * 46 * 81].reshape(n, 46, 9, 9)
         self.mask = np.zeros((n, A), np.uint8)
         self.n_legal = np.zeros(n, np.int32)
         self.reward = np.zeros(n, np.float32)

@@ -35,3 +35,10 @@ def test_emu_random_vs_oracle_drop_heavy():
 def test_emu_random_short_games_many_resets():
     ndone = envcheck.check_random_vs_oracle(make_env, n_games=16, n_steps=150, seed=9, max_moves=40)
     assert ndone >= 16 * 3
+
+
+def test_emu_obs_rows_at_every_alignment_phase():
+    import pytest
+    from tests.emu.emu import EmuEnv
+    for off in (1, 2, 3):
+        envcheck.check_random_vs_oracle(lambda n, mm, off=off: EmuEnv(n, mm, obs_offset=off), n_games=5, n_steps=30, seed=off)

@@ -77,3 +77,26 @@ def test_gpu_full_size_4096_properties():
         assert np.array_equal(obs[:64].cpu().numpy(), o[0])
         assert np.array_equal(envs[0].legal_mask[:64].cpu().numpy().astype(np.uint8), o[1])
         assert np.array_equal(envs[0].done[:64].cpu().numpy().astype(np.uint8), o[4])
+
+
+def test_gpu_outputs_at_every_alignment_phase():
+    """obs rows 4-byte aligned only (float offsets 1..3) and mask rows at odd byte offsets: same results as the oracle."""
+    import torch
+    from oracle import ko
+    from shogidrl_amd.env import VecShogiEnv
+    N = 37
+    for off in (1, 2, 3):
+        env = VecShogiEnv(N, 500)
+        ora = ko.VecGames(N, 500)
+        oflat = torch.zeros(N * 46 * 81 + 8, device="cuda:0")
+        mflat = torch.zeros(N * 13527 + 8, dtype=torch.bool, device="cuda:0")
+        obs = oflat[off:off + N * 46 * 81].view(N, 46, 9, 9)
+        mask = mflat[off:off + N * 13527].view(N, 13527)
+        env.reset(out_obs=obs, out_mask=mask)
+        g = torch.Generator(device="cuda:0").manual_seed(off)
+        for k in range(12):
+            a = (torch.rand(mask.shape, device="cuda:0", generator=g) * mask).argmax(dim=1)
+            env.step(a, out_obs=obs, out_mask=mask)
+            o = ora.step(a.cpu().numpy())
+            assert np.array_equal(obs.cpu().numpy(), o[0]) and np.array_equal(mask.cpu().numpy().astype(np.uint8), o[1]), (off, k)
+        assert float(oflat[:off].abs().sum()) == 0 and float(oflat[off + N * 46 * 81:].abs().sum()) == 0   # no stray writes
