@@ -5,7 +5,7 @@ Host-side mirror of the reference interface for this path:
       (keisei/shogi/shogi_game.py:39-54, 113-130, 216, 574-660, 183)
   PolicyOutputMapper.get_legal_mask (keisei/utils/utils.py:310-336)
   the Gymnasium-style vector env the reference sketches: reset() -> obs[N];
-      step(actions[N]) -> (obs, rewards, terminated, truncated, infos) (docs/1. DESIGN.md:590-602)
+      step(actions[N]) -> (obs, rewards, done, infos) (+ terminated / truncated properties; docs/1. DESIGN.md:590-602)
 All tensors live on the GPU; nothing here synchronises with the host.
 """
 import numpy as np
@@ -19,22 +19,6 @@ REASON_NAMES = ("Game ongoing", "Tsumi", "stalemate", "Max moves reached", "Senn
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
-
-
-class _Lazy:
-    """terminated / truncated flags computed only if somebody looks at them (keeps the hot loop at one launch)."""
-
-    def __init__(self, env, name):
-        self._env, self._name = env, name
-
-    def tensor(self):
-        return getattr(self._env, self._name)
-
-    def __getattr__(self, k):
-        return getattr(self.tensor(), k)
-
-    def __bool__(self):
-        return bool(self.tensor())
 
 
 class VecShogiEnv:
@@ -105,7 +89,9 @@ class VecShogiEnv:
         return self.obs, self.legal_mask
 
     def step(self, actions, validate=True, out_obs=None, out_mask=None, prev_mask=None):
-        """actions: int64 [N] on the device.  Returns (obs, reward, terminated, truncated, info).
+        """actions: int64 [N] on the device.  Returns (obs, reward, done, info) like ShogiGame.make_move
+        (shogi_game.py:553-572), batched; `terminated` / `truncated` (the Gymnasium split the reference sketches in
+        docs/1. DESIGN.md:590-602) are available as properties and computed only when asked for.
 
         out_obs / out_mask: where the kernel writes the next observation / mask (default: the env's own
         buffers); prev_mask: the mask the actions were drawn from (default: the mask of the previous call),
@@ -125,8 +111,7 @@ class VecShogiEnv:
                                    self.reason.data_ptr(), self.winner.data_ptr(), int(self.auto_reset), _stream()),
               "ksh_env_step")
         self.obs, self.legal_mask = obs, mask
-        return obs, self.reward, _Lazy(self, "terminated"), _Lazy(self, "truncated"), \
-            {"reason": self.reason, "winner": self.winner, "n_legal": self.n_legal, "done": self.done}
+        return obs, self.reward, self.done, {"reason": self.reason, "winner": self.winner, "n_legal": self.n_legal}
 
     @property
     def truncated(self):

@@ -52,12 +52,12 @@ def play_games(black, white, num_games, max_moves_per_game=500, device="cuda:0",
     for ply in range(max_moves_per_game):
         player = black if ply % 2 == 0 else white              # all games are in lock-step: same side to move
         a, _, _ = player.select_actions(obs, mask, is_training=not deterministic)
-        obs, _, _, _, info = env.step(a, validate=False)       # finished games ignore further actions (shogi_game.py:589-593)
-        newly = info["done"] & ~over
+        obs, _, done, info = env.step(a, validate=False)       # finished games ignore further actions (shogi_game.py:589-593)
+        newly = done & ~over
         reason = torch.where(newly, info["reason"], reason)
         winner = torch.where(newly, info["winner"], winner)
         length = torch.where(newly, torch.full_like(length, ply + 1), length)
-        over |= info["done"]
+        over |= done
         mask = env.legal_mask
         if ply % 16 == 15 and bool(over.all()):               # one host sync every 16 plies
             break
