@@ -183,3 +183,40 @@ def test_batched_evaluation_games_finish_and_agree_with_oracle():
     assert sum(res.reasons.values()) == 96 and set(res.reasons) <= {"Tsumi", "stalemate", "Max moves reached", "Sennichite"}
     assert 20 <= res.avg_game_length <= 120
     assert res.reasons.get("Tsumi", 0) == res.black_wins + res.white_wins     # only Tsumi produces a winner
+
+
+def test_config0_single_game_episode_plumbing():
+    """BASELINE configs[0]: one ShogiGame self-play episode with the tiny CNN through the reference-style single-game
+    calls (StepManager.execute_step order, step_manager.py:98-348): legal moves -> mask -> select_action -> make_move
+    -> buffer.add; then compute_advantages_and_returns + learn."""
+    from shogidrl_amd.agent import PPOConfig, VecPPOAgent
+    from shogidrl_amd.buffer import ExperienceBuffer
+    from shogidrl_amd.game import ShogiGame
+    from shogidrl_amd.mapper import PolicyOutputMapper
+    from shogidrl_amd.models import TinyActorCritic
+    torch.manual_seed(1)
+    mapper = PolicyOutputMapper()
+    agent = VecPPOAgent(TinyActorCritic(), PPOConfig(ppo_epochs=2, minibatch_size=16, seed=42), DEV)
+    game = ShogiGame(max_moves_per_game=40)
+    buf = ExperienceBuffer(64, 0.99, 0.95, DEV)
+    obs = game.reset()
+    steps, episodes = 0, 0
+    while steps < 64:
+        legal = game.get_legal_moves()
+        assert legal, "a live game always has legal moves"
+        mask = mapper.get_legal_mask(legal, DEV)
+        assert torch.equal(mask, game.get_legal_mask())                 # host-built mask == kernel-built mask
+        move, idx, logp, value = agent.select_action(obs, mask, is_training=True)
+        assert move in legal
+        next_obs, reward, done, info = game.make_move(move)
+        buf.add(torch.as_tensor(obs), idx, reward, logp, value, done, mask)
+        obs = next_obs
+        steps += 1
+        if done:
+            assert info["reason"] in ("Tsumi", "stalemate", "Max moves reached", "Sennichite")
+            episodes += 1
+            obs = game.reset()
+    assert episodes >= 1                                               # max_moves 40 guarantees an episode end
+    buf.compute_advantages_and_returns(agent.get_value(obs))
+    m = agent.learn(buf)
+    assert np.isfinite(list(m.values())).all() and len(buf) == 64
