@@ -149,14 +149,29 @@ class VecPPOAgent:
 
     # ------------------------------------------------------------------ checkpoints (ppo_agent.py:462-537 dict layout)
     def save_model(self, file_path, global_timestep=0, total_episodes_completed=0, stats_to_save=None):
+        """Same dict as the reference: model_state_dict, optimizer_state_dict, global_timestep,
+        total_episodes_completed (+ black_wins / white_wins / draws from stats_to_save)."""
         d = {"model_state_dict": self.model.state_dict(), "optimizer_state_dict": self.optimizer.state_dict(),
              "global_timestep": global_timestep, "total_episodes_completed": total_episodes_completed}
-        d.update(stats_to_save or {})
+        if stats_to_save:
+            d.update(stats_to_save)
         torch.save(d, file_path)
 
     def load_model(self, file_path):
-        ck = torch.load(file_path, map_location=self.device, weights_only=True)
-        self.model.load_state_dict(ck["model_state_dict"])
-        if "optimizer_state_dict" in ck:
+        """Returns the reference's result dict; a missing / broken file yields zeros and an "error" entry
+        (ppo_agent.py:489-537) instead of raising.  Files are read with weights_only=True."""
+        import os
+        blank = {"global_timestep": 0, "total_episodes_completed": 0, "black_wins": 0, "white_wins": 0, "draws": 0}
+        if not (hasattr(file_path, "read") or os.path.exists(file_path)):
+            return dict(blank, error="File not found")
+        try:
+            ck = torch.load(file_path, map_location=self.device, weights_only=True)
+            self.model.load_state_dict(ck["model_state_dict"])
             self.optimizer.load_state_dict(ck["optimizer_state_dict"])
-        return ck
+            return {"global_timestep": ck.get("global_timestep", 0),
+                    "total_episodes_completed": ck.get("total_episodes_completed", 0),
+                    "black_wins": ck.get("black_wins", 0), "white_wins": ck.get("white_wins", 0),
+                    "draws": ck.get("draws", 0), "lr_schedule_type": ck.get("lr_schedule_type", None),
+                    "lr_schedule_step_on": ck.get("lr_schedule_step_on", "epoch")}
+        except (KeyError, RuntimeError, EOFError) as e:
+            return dict(blank, error=str(e))

@@ -263,3 +263,33 @@ def make_learn_e2e():
     np.savez_compressed(os.path.join(HERE, "learn_e2e.npz"), obs_packed=np.packbits(obs.astype(bool).reshape(B, -1), axis=1),
                         mask_packed=np.packbits(mask, axis=1, bitorder="little"), actions=actions, old_logp=old_logp,
                         old_values=old_values, adv=adv, ret=ret, **out)
+
+
+# ----------------------------------------------------------------------------- checkpoint layout
+def make_checkpoint_layout():
+    """State-dict keys / shapes of the reference's networks and the key set of PPOAgent.save_model's dict
+    (ppo_agent.py:462-487), so that reference checkpoints load into shogidrl_amd.models and vice versa."""
+    import io
+    import json
+    from keisei.core.neural_network import ActorCritic
+    from keisei.training.models.resnet_tower import ActorCriticResTower
+    out = {}
+    m = ActorCriticResTower(46, A, tower_depth=9, tower_width=256, se_ratio=0.25)
+    out["resnet_9x256_se025"] = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+    m2 = ActorCriticResTower(46, A, tower_depth=2, tower_width=16, se_ratio=None)
+    out["resnet_2x16_nose"] = [[k, list(v.shape)] for k, v in m2.state_dict().items()]
+    t = ActorCritic(46, A)
+    out["tiny_cnn"] = [[k, list(v.shape)] for k, v in t.state_dict().items()]
+    cfg = load_config()
+    cfg.env.device = "cpu"
+    agent = PPOAgent(m2, cfg, torch.device("cpu"))
+    buf = io.BytesIO()
+    agent.save_model(buf, global_timestep=123, total_episodes_completed=4, stats_to_save={"black_wins": 1, "white_wins": 2, "draws": 1})
+    buf.seek(0)
+    ck = torch.load(buf, weights_only=True)
+    out["save_model_keys"] = sorted(ck.keys())
+    out["optimizer_state_dict_keys"] = sorted(ck["optimizer_state_dict"].keys())
+    out["optimizer_param_group_keys"] = sorted(ck["optimizer_state_dict"]["param_groups"][0].keys())
+    with open(os.path.join(HERE, "checkpoint_layout.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("checkpoint layout:", len(out["resnet_9x256_se025"]), "entries;", out["save_model_keys"])
