@@ -21,7 +21,8 @@ def test_emu_sequences_fixture():
 
 
 def test_emu_traces_fixture():
-    assert envcheck.check_traces(make_env) > 15000
+    # 24 of the 48 golden games here (the GPU suite replays all of them through the C-ABI)
+    assert envcheck.check_traces(make_env, max_games=24) > 7000
 
 
 def test_emu_traces_no_autoreset_terminal_obs():
