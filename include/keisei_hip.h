@@ -95,6 +95,27 @@ int ksh_env_step(void *handle, const int64_t *actions /*dev [N]*/, const uint8_t
                  float *reward /*dev*/, uint8_t *done /*dev*/, uint8_t *reason /*dev*/, int8_t *winner /*dev*/,
                  int auto_reset, void *stream);
 
+/* Bit-packed legal masks (beyond the drop-in contract): the same information as the bool[13527]
+ * mask in 1 696 bytes per game -- uint32 [N][424], bit i of a row <-> action id i (little-endian bit order, i.e.
+ * numpy.packbits(mask, bitorder="little")), rows 16-byte aligned, bits >= 13527 zero.  The *_packed entry points
+ * write / read this form; the byte mask output becomes optional (pass NULL to skip its 13.5 KB per game-step). */
+#define KSH_MASK_WORDS 424
+int ksh_env_reset_packed(void *handle, const uint8_t *reset_mask /*dev or NULL*/, float *obs /*dev*/,
+                         uint8_t *legal_mask /*dev or NULL*/, uint32_t *legal_bits /*dev [N,424]*/, int32_t *n_legal /*dev*/,
+                         void *stream);
+int ksh_env_step_packed(void *handle, const int64_t *actions /*dev*/, const uint32_t *prev_bits /*dev or NULL*/,
+                        float *next_obs /*dev*/, uint8_t *next_mask /*dev or NULL*/, uint32_t *next_bits /*dev [N,424]*/,
+                        int32_t *n_legal /*dev*/, float *reward /*dev*/, uint8_t *done /*dev*/, uint8_t *reason /*dev*/,
+                        int8_t *winner /*dev*/, int auto_reset, void *stream);
+int ksh_masked_sample_packed(const void *logits /*dev [B,A]*/, int logits_dtype, const uint32_t *mask_bits /*dev [B,424]*/,
+                             int B, uint64_t seed, uint64_t step, int deterministic, int64_t *action /*dev*/,
+                             float *log_prob /*dev*/, void *stream);
+int ksh_ppo_loss_fwd_bwd_packed(const void *logits /*dev [B,A]*/, int logits_dtype, const uint32_t *mask_bits /*dev [B,424]*/,
+                                const int64_t *actions, const float *old_log_probs, const float *advantages,
+                                const float *returns, const float *values, const float *old_values, int B, float clip_eps,
+                                float vf_coef, float ent_coef, int value_clip, void *dlogits, float *dvalues, float *stats,
+                                void *workspace, void *stream);
+
 /* Host-side state exchange for tests / fixtures (ShogiGame.from_sfen, shogi_game.py:283-345, is host
  * code: parse the SFEN on the host, then hand the packed 128-byte record over).  Both calls
  * synchronise the given stream.  Record layout: bytes 0-80 board (0 empty, else 1+type+14*color,

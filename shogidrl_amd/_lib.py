@@ -8,6 +8,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SHOGIDRL_AMD_LIB") or os.path.join(PKG, "libkeisei_hip.so")
 
 NUM_ACTIONS = 13527
+MASK_WORDS = 424     # int32 words per row of a bit-packed legal mask (include/keisei_hip.h KSH_MASK_WORDS)
 OBS_SHAPE = (46, 9, 9)
 
 _lib = None
@@ -15,7 +16,7 @@ _lib = None
 # every symbol include/keisei_hip.h declares (tests check the .so exports each of them)
 SYMBOLS = [
     "ksh_last_error", "ksh_version", "ksh_env_create", "ksh_env_destroy", "ksh_env_num_games", "ksh_env_max_moves",
-    "ksh_env_reset", "ksh_env_observe", "ksh_env_evaluate_termination", "ksh_env_step", "ksh_env_set_state", "ksh_env_get_state", "ksh_masked_sample",
+    "ksh_env_reset", "ksh_env_observe", "ksh_env_evaluate_termination", "ksh_env_step", "ksh_env_reset_packed", "ksh_env_step_packed", "ksh_env_set_state", "ksh_env_get_state", "ksh_masked_sample", "ksh_masked_sample_packed", "ksh_ppo_loss_fwd_bwd_packed",
     "ksh_gae_scan", "ksh_ppo_loss_workspace_bytes", "ksh_ppo_loss_fwd_bwd", "ksh_event_create", "ksh_event_record",
     "ksh_event_elapsed_ms", "ksh_event_destroy",
 ]
@@ -52,9 +53,13 @@ def lib():
     L.ksh_env_observe.argtypes = [vp, vp, vp, vp, vp]
     L.ksh_env_evaluate_termination.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.ksh_env_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    L.ksh_env_reset_packed.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.ksh_env_step_packed.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
     L.ksh_env_set_state.argtypes = [vp, i32, vp, vp]
     L.ksh_env_get_state.argtypes = [vp, i32, vp, vp]
     L.ksh_masked_sample.argtypes = [vp, i32, vp, i32, u64, u64, i32, vp, vp, vp]
+    L.ksh_masked_sample_packed.argtypes = [vp, i32, vp, i32, u64, u64, i32, vp, vp, vp]
+    L.ksh_ppo_loss_fwd_bwd_packed.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp]
     L.ksh_gae_scan.argtypes = [vp, vp, vp, vp, f64, f64, i32, i32, vp, vp, vp]
     L.ksh_ppo_loss_workspace_bytes.restype = u64
     L.ksh_ppo_loss_workspace_bytes.argtypes = [i32]

@@ -27,6 +27,7 @@
 #define KSH_OBSF 3726
 #define KSH_WPB 4             // waves (= games) per block
 #define KSH_MASKW 432         // dwords of the per-game legal bit-set (423 used + funnel-shift slack)
+#define KSH_BITROW 424        // dwords per row of the packed legal mask (13 527 bits, rows 16-byte aligned)
 #define KSH_M27 0x7FFFFFFu
 
 // state record byte offsets (include/keisei_hip.h, ksh_env_set_state)
@@ -46,9 +47,11 @@ struct KshStepArgs {
     const KshTables *tables;
     const long long *actions;  // [N] or null (mode != 2)
     const uint8_t *prev_mask;  // [N][A] or null
+    const uint32_t *prev_bits; // [N][KSH_BITROW] packed form of prev_mask, or null
     const uint8_t *reset_mask; // [N] or null (mode 1)
     float *obs;                // [N][46*81]
-    uint8_t *mask;             // [N][A]
+    uint8_t *mask;             // [N][A] one byte per action, or null when only the packed form is wanted
+    uint32_t *mask_bits;       // [N][KSH_BITROW] bit i of a row <-> action id i, or null
     int *n_legal;              // [N]
     float *reward;             // [N] (mode 2)
     uint8_t *done;
@@ -652,6 +655,8 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
             } else {
                 bool ok = act >= 0 && act < KSH_A;
                 if (ok && a.prev_mask != nullptr) ok = a.prev_mask[(size_t)g * KSH_A + (size_t)act] != 0;
+                if (ok && a.prev_bits != nullptr)
+                    ok = ((a.prev_bits[(size_t)g * KSH_BITROW + (size_t)(act >> 5)] >> (int)(act & 31)) & 1u) != 0;
                 int from = -1, to = 0, aux = 0, pcf = 0, pct = 0;
                 if (ok) {
                     const int ai = (int)act;
@@ -834,8 +839,21 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
     if (!obs_written) ksh_write_obs(W, a, g, lane, mf_idx, mf_hint);
     KSH_STAMP(9);
 
+    // ---- packed legal mask (optional): the LDS bit-set as it is, 106 aligned 16-byte stores per game
+    if (a.mask_bits != nullptr) {
+        uint32_t *brow = a.mask_bits + (size_t)g * KSH_BITROW;
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int c = lane + 64 * it;
+            if (c < KSH_BITROW / 4) {
+                uint4 v = {W.maskbits[4 * c], W.maskbits[4 * c + 1], W.maskbits[4 * c + 2], W.maskbits[4 * c + 3]};
+                if (c == KSH_BITROW / 4 - 1) { v.z &= 0x007FFFFFu; v.w = 0u; }   // bits >= 13527 (dword 422 keeps 23) stay zero
+                ksh_store16(brow + 4 * c, v);
+            }
+        }
+    }
     // ---- legal mask: expand the bit-set to one byte per action, 16-byte aligned stores
-    {
+    if (a.mask != nullptr) {
         uint8_t *mrow = a.mask + (size_t)g * KSH_A;
         const size_t addr = reinterpret_cast<size_t>(mrow);
         const int head = (int)((16 - (addr & 15)) & 15);        // bytes before the first aligned chunk

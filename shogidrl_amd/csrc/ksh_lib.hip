@@ -96,8 +96,11 @@ static unsigned long long *g_stamps = nullptr;  // diagnostic builds only (ksh_d
 
 static int launch_env(KshEnv *e, int mode, const int64_t *actions, const uint8_t *prev_mask, const uint8_t *reset_mask,
                       float *obs, uint8_t *mask, int32_t *n_legal, float *reward, uint8_t *done, uint8_t *reason,
-                      int8_t *winner, int auto_reset, void *stream) {
-    if (!obs || !mask || !n_legal) return fail_arg("env: obs / mask / n_legal must not be null");
+                      int8_t *winner, int auto_reset, void *stream, const uint32_t *prev_bits = nullptr,
+                      uint32_t *mask_bits = nullptr) {
+    if (!obs || !n_legal) return fail_arg("env: obs / n_legal must not be null");
+    if (!mask && !mask_bits) return fail_arg("env: give a byte mask, a packed mask, or both");
+    if ((reinterpret_cast<size_t>(mask_bits) & 15) != 0) return fail_arg("env: packed mask must be 16-byte aligned");
     if ((reinterpret_cast<size_t>(obs) & 3) != 0) return fail_arg("env: obs must be 4-byte aligned");
     if (mode == 2 && (!actions || !reward || !done || !reason || !winner)) return fail_arg("env step: null output");
     KshStepArgs a;
@@ -106,6 +109,8 @@ static int launch_env(KshEnv *e, int mode, const int64_t *actions, const uint8_t
     a.tables = e->tables;
     a.actions = reinterpret_cast<const long long *>(actions);
     a.prev_mask = prev_mask;
+    a.prev_bits = prev_bits;
+    a.mask_bits = mask_bits;
     a.reset_mask = reset_mask;
     a.obs = obs;
     a.mask = mask;
@@ -155,6 +160,21 @@ int ksh_env_step(void *handle, const int64_t *actions, const uint8_t *prev_mask,
                       reason, winner, auto_reset, stream);
 }
 
+int ksh_env_reset_packed(void *handle, const uint8_t *reset_mask, float *obs, uint8_t *legal_mask, uint32_t *legal_bits,
+                         int32_t *n_legal, void *stream) {
+    if (!handle) return fail_arg("ksh_env_reset_packed: null handle");
+    return launch_env((KshEnv *)handle, 1, nullptr, nullptr, reset_mask, obs, legal_mask, n_legal, nullptr, nullptr, nullptr,
+                      nullptr, 0, stream, nullptr, legal_bits);
+}
+
+int ksh_env_step_packed(void *handle, const int64_t *actions, const uint32_t *prev_bits, float *next_obs, uint8_t *next_mask,
+                        uint32_t *next_bits, int32_t *n_legal, float *reward, uint8_t *done, uint8_t *reason, int8_t *winner,
+                        int auto_reset, void *stream) {
+    if (!handle) return fail_arg("ksh_env_step_packed: null handle");
+    return launch_env((KshEnv *)handle, 2, actions, nullptr, nullptr, next_obs, next_mask, n_legal, reward, done, reason, winner,
+                      auto_reset, stream, prev_bits, next_bits);
+}
+
 int ksh_env_set_state(void *handle, int game, const uint8_t *state128, void *stream) {
     if (!handle || !state128) return fail_arg("ksh_env_set_state: null argument");
     KshEnv *e = (KshEnv *)handle;
@@ -187,17 +207,32 @@ int ksh_env_get_state(void *handle, int game, uint8_t *state128, void *stream) {
 }
 
 // ---------------------------------------------------------------------------------- PPO-side kernels
+static int sample_impl(const void *logits, int logits_dtype, const uint8_t *mask, const uint32_t *mask_bits, int B,
+                       uint64_t seed, uint64_t step, int deterministic, int64_t *action, float *log_prob, void *stream);
+
 int ksh_masked_sample(const void *logits, int logits_dtype, const uint8_t *mask, int B, uint64_t seed, uint64_t step,
                       int deterministic, int64_t *action, float *log_prob, void *stream) {
-    if (!logits || !mask || !action || !log_prob || B <= 0) return fail_arg("ksh_masked_sample: bad argument");
+    if (!mask) return fail_arg("ksh_masked_sample: bad argument");
+    return sample_impl(logits, logits_dtype, mask, nullptr, B, seed, step, deterministic, action, log_prob, stream);
+}
+
+int ksh_masked_sample_packed(const void *logits, int logits_dtype, const uint32_t *mask_bits, int B, uint64_t seed,
+                             uint64_t step, int deterministic, int64_t *action, float *log_prob, void *stream) {
+    if (!mask_bits) return fail_arg("ksh_masked_sample_packed: bad argument");
+    return sample_impl(logits, logits_dtype, nullptr, mask_bits, B, seed, step, deterministic, action, log_prob, stream);
+}
+
+static int sample_impl(const void *logits, int logits_dtype, const uint8_t *mask, const uint32_t *mask_bits, int B,
+                       uint64_t seed, uint64_t step, int deterministic, int64_t *action, float *log_prob, void *stream) {
+    if (!logits || !action || !log_prob || B <= 0) return fail_arg("ksh_masked_sample: bad argument");
     if (logits_dtype != 0 && logits_dtype != 1) return fail_arg("ksh_masked_sample: logits_dtype must be 0 (f32) or 1 (bf16)");
     const dim3 grid((B + KSH_SAMPLE_WPB - 1) / KSH_SAMPLE_WPB), block(64 * KSH_SAMPLE_WPB);
     if (logits_dtype == 0)
         hipLaunchKernelGGL(ksh_masked_sample_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float *)logits, mask,
-                           B, seed, step, deterministic, reinterpret_cast<long long *>(action), log_prob);
+                           mask_bits, B, seed, step, deterministic, reinterpret_cast<long long *>(action), log_prob);
     else
         hipLaunchKernelGGL(ksh_masked_sample_kernel<ksh_bf16>, grid, block, 0, (hipStream_t)stream,
-                           (const ksh_bf16 *)logits, mask, B, seed, step, deterministic,
+                           (const ksh_bf16 *)logits, mask, mask_bits, B, seed, step, deterministic,
                            reinterpret_cast<long long *>(action), log_prob);
     HIP_TRY(hipGetLastError());
     return KSH_OK;
@@ -218,17 +253,42 @@ int ksh_gae_scan(const float *rewards, const float *values, const uint8_t *dones
 
 uint64_t ksh_ppo_loss_workspace_bytes(int B) { return (uint64_t)(B > 0 ? B : 0) * 8 * sizeof(float) + 64; }
 
+static int loss_impl(const void *logits, int logits_dtype, const uint8_t *mask, const uint32_t *mask_bits,
+                     const int64_t *actions, const float *old_log_probs, const float *advantages, const float *returns,
+                     const float *values, const float *old_values, int B, float clip_eps, float vf_coef, float ent_coef,
+                     int value_clip, void *dlogits, float *dvalues, float *stats, void *workspace, void *stream);
+
 int ksh_ppo_loss_fwd_bwd(const void *logits, int logits_dtype, const uint8_t *mask, const int64_t *actions,
                          const float *old_log_probs, const float *advantages, const float *returns, const float *values,
                          const float *old_values, int B, float clip_eps, float vf_coef, float ent_coef, int value_clip,
                          void *dlogits, float *dvalues, float *stats, void *workspace, void *stream) {
-    if (!logits || !mask || !actions || !old_log_probs || !advantages || !returns || !values || !dlogits || !dvalues ||
+    if (!mask) return fail_arg("ksh_ppo_loss_fwd_bwd: bad argument");
+    return loss_impl(logits, logits_dtype, mask, nullptr, actions, old_log_probs, advantages, returns, values, old_values, B,
+                     clip_eps, vf_coef, ent_coef, value_clip, dlogits, dvalues, stats, workspace, stream);
+}
+
+int ksh_ppo_loss_fwd_bwd_packed(const void *logits, int logits_dtype, const uint32_t *mask_bits, const int64_t *actions,
+                                const float *old_log_probs, const float *advantages, const float *returns,
+                                const float *values, const float *old_values, int B, float clip_eps, float vf_coef,
+                                float ent_coef, int value_clip, void *dlogits, float *dvalues, float *stats, void *workspace,
+                                void *stream) {
+    if (!mask_bits) return fail_arg("ksh_ppo_loss_fwd_bwd_packed: bad argument");
+    return loss_impl(logits, logits_dtype, nullptr, mask_bits, actions, old_log_probs, advantages, returns, values, old_values,
+                     B, clip_eps, vf_coef, ent_coef, value_clip, dlogits, dvalues, stats, workspace, stream);
+}
+
+static int loss_impl(const void *logits, int logits_dtype, const uint8_t *mask, const uint32_t *mask_bits,
+                     const int64_t *actions, const float *old_log_probs, const float *advantages, const float *returns,
+                     const float *values, const float *old_values, int B, float clip_eps, float vf_coef, float ent_coef,
+                     int value_clip, void *dlogits, float *dvalues, float *stats, void *workspace, void *stream) {
+    if (!logits || !actions || !old_log_probs || !advantages || !returns || !values || !dlogits || !dvalues ||
         !stats || !workspace || B <= 0)
         return fail_arg("ksh_ppo_loss_fwd_bwd: bad argument");
     if (value_clip && !old_values) return fail_arg("ksh_ppo_loss_fwd_bwd: value_clip needs old_values");
     if (logits_dtype != 0 && logits_dtype != 1) return fail_arg("ksh_ppo_loss_fwd_bwd: logits_dtype must be 0 or 1");
     KshLossArgs a;
     a.mask = mask;
+    a.mask_bits = mask_bits;
     a.actions = reinterpret_cast<const long long *>(actions);
     a.old_logp = old_log_probs;
     a.adv = advantages;

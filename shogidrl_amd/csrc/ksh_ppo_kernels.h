@@ -17,6 +17,7 @@
 #define KSH_PA 13527
 #define KSH_ROW_THREADS 256
 #define KSH_BITW 432
+#define KSH_PBITROW 424   // dwords per row of a packed mask (matches KSH_BITROW of the env kernel)
 
 typedef __bf16 ksh_bf16;
 
@@ -109,6 +110,12 @@ __device__ __forceinline__ void ksh_build_bits(KshRowLds &R, const uint8_t *__re
         const int b = tail0 + tid;
         if (mrow[b]) atomicOr(&R.bits[b >> 5], 1u << (b & 31));
     }
+    __syncthreads();
+}
+
+// Packed-mask variant: the row already is the bit-set (424 dwords, 16-byte aligned rows).
+__device__ __forceinline__ void ksh_load_bits(KshRowLds &R, const uint32_t *__restrict__ brow, int tid) {
+    for (int i = tid; i < KSH_BITW; i += KSH_ROW_THREADS) R.bits[i] = i < KSH_PBITROW ? brow[i] : 0u;
     __syncthreads();
 }
 
@@ -253,13 +260,14 @@ __device__ __forceinline__ void ksh_sample_visit(KshSampleAcc &A, const T *row, 
 
 template <typename T>
 __global__ void __launch_bounds__(64 * KSH_SAMPLE_WPB)
-ksh_masked_sample_kernel(const T *__restrict__ logits, const uint8_t *__restrict__ mask, int B, unsigned long long seed,
+ksh_masked_sample_kernel(const T *__restrict__ logits, const uint8_t *__restrict__ mask,
+                         const uint32_t *__restrict__ mask_bits, int B, unsigned long long seed,
                          unsigned long long step, int deterministic, long long *__restrict__ action,
                          float *__restrict__ log_prob) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * KSH_SAMPLE_WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (b >= B) return;  // wave-uniform
-    const uint8_t *mrow = mask + (size_t)b * KSH_PA;
+    const uint8_t *mrow = mask + (mask_bits != nullptr ? (size_t)0 : (size_t)b * KSH_PA);
     const T *row = logits + (size_t)b * KSH_PA;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const uint32_t s0 = (uint32_t)step, s1 = (uint32_t)(step >> 32);
@@ -280,32 +288,53 @@ ksh_masked_sample_kernel(const T *__restrict__ logits, const uint8_t *__restrict
         else ksh_sample_visit<T>(A, row, j, b, det, s0, s1, k0, k1);
     };
 
-    const size_t addr = reinterpret_cast<size_t>(mrow);
-    const int head = (int)((16 - (addr & 15)) & 15);
-    const int nfull = (KSH_PA - head) >> 4;               // 844 or 845 aligned chunks
-    const int tail0 = head + 16 * nfull;
-    if (lane < head && mrow[lane]) push(lane);
-    if (lane < KSH_PA - tail0 && mrow[tail0 + lane]) push(tail0 + lane);
-    for (int half = 0; half < 2; half++) {                 // 2 x 7 x 64 = 896 >= 845 chunks, 7 loads in flight per lane
-        uint4 ch[7];
+    if (mask_bits != nullptr) {
+        // packed rows: 424 dwords per row, 7 per lane; every set bit is a legal id
+        const uint32_t *brow = mask_bits + (size_t)b * KSH_PBITROW;
+        uint32_t wd[7];
 #pragma unroll
         for (int it = 0; it < 7; it++) {
-            const int c = lane + 64 * (7 * half + it);
-            ch[it] = uint4{0u, 0u, 0u, 0u};
-            if (c < nfull) ch[it] = *reinterpret_cast<const uint4 *>(mrow + head + 16 * c);
+            const int i = lane + 64 * it;
+            wd[it] = i < KSH_PBITROW ? brow[i] : 0u;
         }
 #pragma unroll
         for (int it = 0; it < 7; it++) {
-            const uint32_t any = ch[it].x | ch[it].y | ch[it].z | ch[it].w;
-            if (any != 0u) {
-                const int j0 = head + 16 * (lane + 64 * (7 * half + it));
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    uint32_t v = q == 0 ? ch[it].x : (q == 1 ? ch[it].y : (q == 2 ? ch[it].z : ch[it].w));
-                    while (v) {                             // visit the non-zero bytes of this dword
-                        const int byte = (__ffs((int)v) - 1) >> 3;
-                        v &= ~(0xFFu << (8 * byte));
-                        push(j0 + 4 * q + byte);
+            uint32_t v = wd[it];
+            const int j0 = 32 * (lane + 64 * it);
+            while (v) {
+                const int bit = __ffs((int)v) - 1;
+                v &= v - 1u;
+                if (j0 + bit < KSH_PA) push(j0 + bit);
+            }
+        }
+    } else {
+        const size_t addr = reinterpret_cast<size_t>(mrow);
+        const int head = (int)((16 - (addr & 15)) & 15);
+        const int nfull = (KSH_PA - head) >> 4;               // 844 or 845 aligned chunks
+        const int tail0 = head + 16 * nfull;
+        if (lane < head && mrow[lane]) push(lane);
+        if (lane < KSH_PA - tail0 && mrow[tail0 + lane]) push(tail0 + lane);
+        for (int half = 0; half < 2; half++) {                 // 2 x 7 x 64 = 896 >= 845 chunks, 7 loads in flight per lane
+            uint4 ch[7];
+    #pragma unroll
+            for (int it = 0; it < 7; it++) {
+                const int c = lane + 64 * (7 * half + it);
+                ch[it] = uint4{0u, 0u, 0u, 0u};
+                if (c < nfull) ch[it] = *reinterpret_cast<const uint4 *>(mrow + head + 16 * c);
+            }
+    #pragma unroll
+            for (int it = 0; it < 7; it++) {
+                const uint32_t any = ch[it].x | ch[it].y | ch[it].z | ch[it].w;
+                if (any != 0u) {
+                    const int j0 = head + 16 * (lane + 64 * (7 * half + it));
+    #pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        uint32_t v = q == 0 ? ch[it].x : (q == 1 ? ch[it].y : (q == 2 ? ch[it].z : ch[it].w));
+                        while (v) {                             // visit the non-zero bytes of this dword
+                            const int byte = (__ffs((int)v) - 1) >> 3;
+                            v &= ~(0xFFu << (8 * byte));
+                            push(j0 + 4 * q + byte);
+                        }
                     }
                 }
             }
@@ -349,7 +378,8 @@ ksh_masked_sample_kernel(const T *__restrict__ logits, const uint8_t *__restrict
 
 // ------------------------------------------------------------------------------------------ PPO loss
 struct KshLossArgs {
-    const uint8_t *mask;
+    const uint8_t *mask;         // one byte per action ...
+    const uint32_t *mask_bits;   // ... or packed rows (exactly one of the two is non-null)
     const long long *actions;
     const float *old_logp;
     const float *adv;
@@ -370,7 +400,8 @@ ksh_ppo_loss_kernel(KshLossArgs a, const T *__restrict__ logits, T *__restrict__
     __shared__ KshRowLds R;
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
-    ksh_build_bits(R, a.mask + (size_t)b * KSH_PA, tid);
+    if (a.mask_bits != nullptr) ksh_load_bits(R, a.mask_bits + (size_t)b * KSH_PBITROW, tid);
+    else ksh_build_bits(R, a.mask + (size_t)b * KSH_PA, tid);
     const T *row = logits + (size_t)b * KSH_PA;
     T *drow = dlogits + (size_t)b * KSH_PA;
     const int act = (int)a.actions[b];

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import NUM_ACTIONS, check, lib
+from ._lib import MASK_WORDS, NUM_ACTIONS, check, lib
 
 REASON_NAMES = ("Game ongoing", "Tsumi", "stalemate", "Max moves reached", "Sennichite", "illegal_move")
 
@@ -22,7 +22,10 @@ def _stream():
 
 
 class VecShogiEnv:
-    def __init__(self, num_games, max_moves_per_game=500, device="cuda:0", auto_reset=True):
+    def __init__(self, num_games, max_moves_per_game=500, device="cuda:0", auto_reset=True, packed_masks=False):
+        """packed_masks=True: the kernel writes legal masks ONLY in the bit-packed form (`legal_bits`, int32 [N,424],
+        1 696 B instead of 13 527 B per game-step); `legal_mask` is then unavailable, and the sampler /
+        loss ops accept the packed tensor directly."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.KeiseiHipError("VecShogiEnv runs on an MI355X only (device=%r); there is no CPU path" % (device,))
@@ -38,7 +41,9 @@ class VecShogiEnv:
         self._h = h
         n, dev = self.num_games, self.device
         self.obs = torch.empty((n, 46, 9, 9), dtype=torch.float32, device=dev)
-        self.legal_mask = torch.empty((n, NUM_ACTIONS), dtype=torch.bool, device=dev)
+        self.packed_masks = bool(packed_masks)
+        self.legal_mask = None if self.packed_masks else torch.empty((n, NUM_ACTIONS), dtype=torch.bool, device=dev)
+        self.legal_bits = torch.empty((n, MASK_WORDS), dtype=torch.int32, device=dev) if self.packed_masks else None
         self.n_legal = torch.empty(n, dtype=torch.int32, device=dev)
         self.reward = torch.zeros(n, dtype=torch.float32, device=dev)
         self.done = torch.zeros(n, dtype=torch.bool, device=dev)
@@ -63,12 +68,19 @@ class VecShogiEnv:
 
     # ------------------------------------------------------------------ API
     def reset(self, reset_mask=None, out_obs=None, out_mask=None):
-        """Reset all games (or those where reset_mask is True). Returns (obs, legal_mask)."""
+        """Reset all games (or those where reset_mask is True). Returns (obs, legal mask [bool, or packed bits])."""
         rm = None
         if reset_mask is not None:
             rm = reset_mask.to(device=self.device, dtype=torch.uint8).contiguous()
         if out_obs is not None:
             self.obs = out_obs
+        if self.packed_masks:
+            if out_mask is not None:
+                self.legal_bits = out_mask
+            check(self._L.ksh_env_reset_packed(self._h, rm.data_ptr() if rm is not None else None, self.obs.data_ptr(), None,
+                                               self.legal_bits.data_ptr(), self.n_legal.data_ptr(), _stream()),
+                  "ksh_env_reset_packed")
+            return self.obs, self.legal_bits
         if out_mask is not None:
             self.legal_mask = out_mask
         check(self._L.ksh_env_reset(self._h, rm.data_ptr() if rm is not None else None, self.obs.data_ptr(),
@@ -76,6 +88,8 @@ class VecShogiEnv:
         return self.obs, self.legal_mask
 
     def observe(self):
+        if self.packed_masks:
+            raise NotImplementedError("observe() re-encodes byte masks; use a byte-mask env for state inspection")
         check(self._L.ksh_env_observe(self._h, self.obs.data_ptr(), self.legal_mask.data_ptr(), self.n_legal.data_ptr(),
                                       _stream()), "ksh_env_observe")
         return self.obs, self.legal_mask
@@ -100,6 +114,17 @@ class VecShogiEnv:
             raise ValueError("actions must be an int64 tensor of shape [%d] on %s" % (self.num_games, self.device))
         actions = actions.contiguous()
         obs = self.obs if out_obs is None else out_obs
+        if self.packed_masks:
+            bits = self.legal_bits if out_mask is None else out_mask
+            if not obs.is_contiguous() or not bits.is_contiguous() or bits.dtype != torch.int32:
+                raise ValueError("out_obs / out_mask must be contiguous (packed masks: int32 [N,424])")
+            prev = (self.legal_bits if prev_mask is None else prev_mask).data_ptr() if validate else None
+            check(self._L.ksh_env_step_packed(self._h, actions.data_ptr(), prev, obs.data_ptr(), None, bits.data_ptr(),
+                                              self.n_legal.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(),
+                                              self.reason.data_ptr(), self.winner.data_ptr(), int(self.auto_reset), _stream()),
+                  "ksh_env_step_packed")
+            self.obs, self.legal_bits = obs, bits
+            return obs, self.reward, self.done, {"reason": self.reason, "winner": self.winner, "n_legal": self.n_legal}
         mask = self.legal_mask if out_mask is None else out_mask
         if not obs.is_contiguous() or not mask.is_contiguous():
             raise ValueError("out_obs / out_mask must be contiguous")

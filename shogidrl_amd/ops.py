@@ -7,7 +7,7 @@
 """
 import torch
 
-from ._lib import NUM_ACTIONS, KeiseiHipError, check, lib
+from ._lib import MASK_WORDS, NUM_ACTIONS, KeiseiHipError, check, lib
 
 
 def _stream():
@@ -30,19 +30,48 @@ def _dtype_code(t):
 
 def _mask_u8(mask):
     if mask.dtype not in (torch.bool, torch.uint8):
-        raise TypeError("legal mask must be bool or uint8")
+        raise TypeError("legal mask must be bool / uint8 [B,13527] or bit-packed int32 [B,424]")
     return mask.contiguous()
+
+
+def is_packed(mask):
+    """bit-packed legal mask: int32 [B, 424], bit i of a row <-> action id i"""
+    return mask.dtype == torch.int32 and mask.shape[-1] == MASK_WORDS
+
+
+def pack_mask(mask):
+    """bool [B,13527] -> int32 [B,424] (host-side helper for tests / interop; the env kernel writes this form itself)"""
+    B = mask.shape[0]
+    m = torch.zeros((B, MASK_WORDS * 32), dtype=torch.bool, device=mask.device)
+    m[:, :NUM_ACTIONS] = mask.to(torch.bool)
+    w = (m.view(B, MASK_WORDS, 32).to(torch.int64) << torch.arange(32, device=mask.device)).sum(-1)
+    return w.to(torch.int32)     # two's-complement wrap of the 32-bit pattern
+
+
+def unpack_mask(bits):
+    """int32 [B,424] -> bool [B,13527]"""
+    B = bits.shape[0]
+    w = bits.to(torch.int64) & 0xFFFFFFFF
+    m = ((w.unsqueeze(-1) >> torch.arange(32, device=bits.device)) & 1).to(torch.bool)
+    return m.view(B, MASK_WORDS * 32)[:, :NUM_ACTIONS].contiguous()
 
 
 def masked_sample(logits, legal_mask, seed, step, deterministic=False):
     """logits [B,13527] f32|bf16, legal_mask [B,13527] bool -> (action int64 [B], log_prob f32 [B])."""
     _need_cuda(logits, legal_mask)
     B = logits.shape[0]
-    assert logits.shape == (B, NUM_ACTIONS) and legal_mask.shape == (B, NUM_ACTIONS)
     logits = logits.contiguous()
-    legal_mask = _mask_u8(legal_mask)
     action = torch.empty(B, dtype=torch.int64, device=logits.device)
     logp = torch.empty(B, dtype=torch.float32, device=logits.device)
+    if is_packed(legal_mask):
+        assert logits.shape == (B, NUM_ACTIONS) and legal_mask.shape == (B, MASK_WORDS)
+        legal_mask = legal_mask.contiguous()
+        check(lib().ksh_masked_sample_packed(logits.data_ptr(), _dtype_code(logits), legal_mask.data_ptr(), B, int(seed),
+                                             int(step), int(bool(deterministic)), action.data_ptr(), logp.data_ptr(),
+                                             _stream()), "ksh_masked_sample_packed")
+        return action, logp
+    assert logits.shape == (B, NUM_ACTIONS) and legal_mask.shape == (B, NUM_ACTIONS)
+    legal_mask = _mask_u8(legal_mask)
     check(lib().ksh_masked_sample(logits.data_ptr(), _dtype_code(logits), legal_mask.data_ptr(), B, int(seed), int(step),
                                   int(bool(deterministic)), action.data_ptr(), logp.data_ptr(), _stream()),
           "ksh_masked_sample")
@@ -74,7 +103,8 @@ class _PPOLossFn(torch.autograd.Function):
         B = logits.shape[0]
         logits_c = logits.contiguous()
         values_c = values.contiguous().float()
-        mask = _mask_u8(legal_mask)
+        packed = is_packed(legal_mask)
+        mask = legal_mask.contiguous() if packed else _mask_u8(legal_mask)
         f = lambda t: t.contiguous().float()
         dlogits = torch.empty_like(logits_c)
         dvalues = torch.empty(B, dtype=torch.float32, device=logits.device)
@@ -82,12 +112,13 @@ class _PPOLossFn(torch.autograd.Function):
         L = lib()
         ws = torch.empty(int(L.ksh_ppo_loss_workspace_bytes(B)), dtype=torch.uint8, device=logits.device)
         ov = f(old_values) if old_values is not None else None
-        check(L.ksh_ppo_loss_fwd_bwd(logits_c.data_ptr(), _dtype_code(logits_c), mask.data_ptr(),
+        fn = L.ksh_ppo_loss_fwd_bwd_packed if packed else L.ksh_ppo_loss_fwd_bwd
+        check(fn(logits_c.data_ptr(), _dtype_code(logits_c), mask.data_ptr(),
                                      actions.contiguous().data_ptr(), f(old_log_probs).data_ptr(), f(advantages).data_ptr(),
                                      f(returns).data_ptr(), values_c.data_ptr(), ov.data_ptr() if ov is not None else None,
                                      B, float(clip_eps), float(vf_coef), float(ent_coef), int(bool(value_clip)),
                                      dlogits.data_ptr(), dvalues.data_ptr(), stats.data_ptr(), ws.data_ptr(), _stream()),
-              "ksh_ppo_loss_fwd_bwd")
+              "ksh_ppo_loss_fwd_bwd_packed" if packed else "ksh_ppo_loss_fwd_bwd")
         ctx.save_for_backward(dlogits, dvalues)
         ctx.values_dtype = values.dtype
         ctx.mark_non_differentiable(stats)

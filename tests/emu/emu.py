@@ -12,7 +12,7 @@ A = 13527
 def _lib():
     subprocess.check_call(["make", "-C", _DIR, "-s"])
     L = C.CDLL(os.path.join(_DIR, "libksh_emu.so"))
-    L.emu_env_launch.argtypes = [C.c_void_p] * 13 + [C.c_int] * 5
+    L.emu_env_launch.argtypes = [C.c_void_p] * 15 + [C.c_int] * 5
     L.emu_build_tables.argtypes = [C.c_void_p, C.c_int]
     L.emu_finish_record.argtypes = [C.c_void_p, C.c_int]
     L.emu_full_hash.argtypes = [C.c_void_p]
@@ -33,6 +33,8 @@ class EmuEnv:
         self._obs_store = np.zeros(n * 46 * 81 + 8, np.float32)
         self.obs = self._obs_store[obs_offset:obs_offset + n * 46 * 81].reshape(n, 46, 9, 9)
         self.mask = np.zeros((n, A), np.uint8)
+        self.bits = np.zeros((n, 424), np.uint32)
+        self.packed_only = False        # True: the kernel writes ONLY the packed mask (byte mask pointer NULL)
         self.n_legal = np.zeros(n, np.int32)
         self.reward = np.zeros(n, np.float32)
         self.done = np.zeros(n, np.uint8)
@@ -43,21 +45,39 @@ class EmuEnv:
         p = lambda x: None if x is None else x.ctypes.data
         self.obs[:] = -7.0          # poison: every byte must be rewritten
         self.mask[:] = 0xCC
-        self.L.emu_env_launch(p(self.state), p(self.hist), p(self.tables), p(actions), p(prev_mask), p(reset_mask),
-                              p(self.obs), p(self.mask), p(self.n_legal), p(self.reward), p(self.done),
+        self.bits[:] = 0xDEADBEEF
+        prev_bits = None
+        if self.packed_only and prev_mask is not None:
+            prev_bits = np.ascontiguousarray(np.packbits(np.pad(prev_mask.astype(bool), ((0, 0), (0, 424 * 32 - A))), axis=1,
+                                                         bitorder="little").view(np.uint32))
+            prev_mask = None
+        self.L.emu_env_launch(p(self.state), p(self.hist), p(self.tables), p(actions), p(prev_mask), p(prev_bits), p(reset_mask),
+                              p(self.obs), None if self.packed_only else p(self.mask), p(self.bits), p(self.n_legal), p(self.reward), p(self.done),
                               p(self.reason), p(self.winner), self.n, self.max_moves, self.cap, mode, auto_reset)
+
+    def _sync_masks(self):
+        """packed and byte forms must describe the same set; in packed-only mode rebuild the byte view from the bits"""
+        unpacked = np.unpackbits(self.bits.view(np.uint8), axis=1, bitorder="little")
+        assert not unpacked[:, A:].any(), "bits beyond action 13526 must be zero"
+        if self.packed_only:
+            self.mask[:] = unpacked[:, :A]
+        else:
+            assert np.array_equal(unpacked[:, :A], self.mask), "packed mask != byte mask"
 
     def reset(self, reset_mask=None):
         rm = None if reset_mask is None else np.ascontiguousarray(reset_mask, np.uint8)
         self._launch(1, reset_mask=rm)
+        self._sync_masks()
         return self.obs.copy(), self.mask.copy(), self.n_legal.copy()
 
     def observe(self):
         self._launch(0)
+        self._sync_masks()
         return self.obs.copy(), self.mask.copy(), self.n_legal.copy()
 
     def evaluate_termination(self):
         self._launch(3)
+        self._sync_masks()
         return (self.obs.copy(), self.mask.copy(), self.n_legal.copy(), self.done.copy(), self.reason.copy(),
                 self.winner.copy())
 
@@ -65,6 +85,7 @@ class EmuEnv:
         a = np.ascontiguousarray(actions, np.int64)
         pm = self.mask.copy() if check_prev else None
         self._launch(2, actions=a, prev_mask=pm, auto_reset=int(auto_reset))
+        self._sync_masks()
         return (self.obs.copy(), self.mask.copy(), self.n_legal.copy(), self.reward.copy(), self.done.copy(),
                 self.reason.copy(), self.winner.copy())
 
@@ -88,9 +109,9 @@ class EmuEnv:
 def _plib():
     L = _lib()
     L.emu_gae.argtypes = [C.c_void_p] * 4 + [C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    L.emu_masked_sample.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int,
+    L.emu_masked_sample.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int,
                                     C.c_void_p, C.c_void_p]
-    L.emu_ppo_loss.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_float, C.c_float, C.c_float,
+    L.emu_ppo_loss.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_float, C.c_float, C.c_float,
                                                                           C.c_int] + [C.c_void_p] * 4
     return L
 
@@ -104,8 +125,15 @@ def from_bf16_bits(b):
     return (b.astype(np.uint32) << 16).view(np.float32)
 
 
+def pack_mask(mask):
+    """bool/uint8 [B,13527] -> uint32 [B,424], bit i of a row <-> action i"""
+    m = np.pad(np.asarray(mask).astype(bool), ((0, 0), (0, 424 * 32 - A)))
+    return np.ascontiguousarray(np.packbits(m, axis=1, bitorder="little").view(np.uint32))
+
+
 class EmuOps:
     """numpy front-end with the same call shapes as tests use for the HIP library."""
+    packed = False      # True: hand the kernels bit-packed masks instead of byte masks
 
     def gae(self, r, v, d, last_v, gamma, lam):
         r = np.ascontiguousarray(r, np.float32); v = np.ascontiguousarray(v, np.float32)
@@ -123,7 +151,9 @@ class EmuOps:
         buf = np.zeros(lg.size + 16, lg.dtype); buf[offset:offset + lg.size] = lg.ravel()
         mb = np.zeros(mask.size + 16, np.uint8); mb[offset:offset + mask.size] = mask.astype(np.uint8).ravel()
         act = np.zeros(B, np.int64); lp = np.zeros(B, np.float32)
-        _plib().emu_masked_sample(buf.ctypes.data + offset * buf.itemsize, int(bf16), mb.ctypes.data + offset, B,
+        bits = pack_mask(mask) if self.packed else None
+        _plib().emu_masked_sample(buf.ctypes.data + offset * buf.itemsize, int(bf16),
+                                  None if self.packed else mb.ctypes.data + offset, None if bits is None else bits.ctypes.data, B,
                                   seed, step, int(deterministic), act.ctypes.data, lp.ctypes.data)
         return act, lp
 
@@ -137,7 +167,9 @@ class EmuOps:
         a64 = np.ascontiguousarray(actions, np.int64)
         ol, ad, rt, vl, ov = f(old_logp), f(adv), f(ret), f(values), f(old_values)
         dv = np.zeros(B, np.float32); st = np.zeros(8, np.float32); ws = np.zeros(B * 8 + 16, np.float32)
-        _plib().emu_ppo_loss(lg.ctypes.data, int(bf16), m8.ctypes.data, a64.ctypes.data, ol.ctypes.data, ad.ctypes.data,
+        bits = pack_mask(mask) if self.packed else None
+        _plib().emu_ppo_loss(lg.ctypes.data, int(bf16), None if self.packed else m8.ctypes.data,
+                             None if bits is None else bits.ctypes.data, a64.ctypes.data, ol.ctypes.data, ad.ctypes.data,
                              rt.ctypes.data, vl.ctypes.data, ov.ctypes.data, B, clip_eps, vf, ent, int(value_clip),
                              dl.ctypes.data, dv.ctypes.data, st.ctypes.data, ws.ctypes.data)
         return (from_bf16_bits(dl) if bf16 else dl), dv, st

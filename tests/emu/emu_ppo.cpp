@@ -7,10 +7,10 @@ namespace {
 struct GaeA { const float *r, *v; const uint8_t *d; const float *lv; float g, gl; int T, N; float *adv, *ret; } ga;
 void gae_entry(void *) { ksh_gae_kernel(ga.r, ga.v, ga.d, ga.lv, ga.g, ga.gl, ga.T, ga.N, ga.adv, ga.ret); }
 
-struct SampA { const void *logits; int dtype; const uint8_t *mask; int B; unsigned long long seed, step; int det; long long *act; float *lp; } sa;
+struct SampA { const void *logits; int dtype; const uint8_t *mask; const uint32_t *bits; int B; unsigned long long seed, step; int det; long long *act; float *lp; } sa;
 void samp_entry(void *) {
-    if (sa.dtype == 0) ksh_masked_sample_kernel<float>((const float *)sa.logits, sa.mask, sa.B, sa.seed, sa.step, sa.det, sa.act, sa.lp);
-    else ksh_masked_sample_kernel<ksh_bf16>((const ksh_bf16 *)sa.logits, sa.mask, sa.B, sa.seed, sa.step, sa.det, sa.act, sa.lp);
+    if (sa.dtype == 0) ksh_masked_sample_kernel<float>((const float *)sa.logits, sa.mask, sa.bits, sa.B, sa.seed, sa.step, sa.det, sa.act, sa.lp);
+    else ksh_masked_sample_kernel<ksh_bf16>((const ksh_bf16 *)sa.logits, sa.mask, sa.bits, sa.B, sa.seed, sa.step, sa.det, sa.act, sa.lp);
 }
 KshLossArgs la;
 const void *l_logits; void *l_dlogits; int l_dtype;
@@ -27,15 +27,15 @@ void emu_gae(const float *r, const float *v, const uint8_t *d, const float *lv, 
     ga = GaeA{r, v, d, lv, (float)gamma, (float)(gamma * lam), T, N, adv, ret};
     for (int b = 0; b < (N + 255) / 256; b++) emu::run_block(gae_entry, nullptr, b, 256);
 }
-void emu_masked_sample(const void *logits, int dtype, const uint8_t *mask, int B, unsigned long long seed,
+void emu_masked_sample(const void *logits, int dtype, const uint8_t *mask, const uint32_t *bits, int B, unsigned long long seed,
                        unsigned long long step, int det, long long *action, float *logp) {
-    sa = SampA{logits, dtype, mask, B, seed, step, det, action, logp};
+    sa = SampA{logits, dtype, mask, bits, B, seed, step, det, action, logp};
     for (int b = 0; b < (B + KSH_SAMPLE_WPB - 1) / KSH_SAMPLE_WPB; b++) emu::run_block(samp_entry, nullptr, b, 64 * KSH_SAMPLE_WPB);
 }
-void emu_ppo_loss(const void *logits, int dtype, const uint8_t *mask, const long long *actions, const float *old_logp,
+void emu_ppo_loss(const void *logits, int dtype, const uint8_t *mask, const uint32_t *bits, const long long *actions, const float *old_logp,
                   const float *adv, const float *ret, const float *values, const float *old_values, int B, float clip_eps,
                   float vf, float ent, int value_clip, void *dlogits, float *dvalues, float *stats, float *workspace) {
-    la.mask = mask; la.actions = actions; la.old_logp = old_logp; la.adv = adv; la.ret = ret; la.values = values;
+    la.mask = mask; la.mask_bits = bits; la.actions = actions; la.old_logp = old_logp; la.adv = adv; la.ret = ret; la.values = values;
     la.old_values = old_values; la.B = B; la.clip_eps = clip_eps; la.vf_coef = vf; la.ent_coef = ent;
     la.value_clip = value_clip; la.dvalues = dvalues; la.stats = stats; la.partial = workspace;
     l_logits = logits; l_dlogits = dlogits; l_dtype = dtype;

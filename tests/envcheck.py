@@ -180,3 +180,31 @@ def check_random_vs_oracle(make_env, n_games, n_steps, seed, max_moves=500, drop
         if hasattr(env, "check_hashes"):
             env.check_hashes()
     return ndone
+
+
+def check_illegal_actions(make_env):
+    """Actions outside the legal set are rejected the way StepManager treats the reference's ValueError
+    (step_manager.py:303-348): done with reason 5, the episode restarts (auto-reset) or the state stays untouched."""
+    init = ko.Game()
+    init_obs, init_ids = init.observation(), init.legal_ids().tolist()
+    bad = [0, 1, 13526, -1, 13527, 10 ** 12, 12960]       # illegal ids in the start position + out-of-range ids
+    env = make_env(len(bad), 500)
+    env.reset()
+    # first make one legal move everywhere so that a reset is observable
+    obs, mask, nl, *_ = env.step(np.full(len(bad), init_ids[0], np.int64), auto_reset=True, check_prev=True)
+    before_obs, before_mask = obs.copy(), mask.copy()
+    obs, mask, nl, rew, done, reason, winner = env.step(np.asarray(bad, np.int64), auto_reset=True, check_prev=True)
+    assert done.tolist() == [1] * len(bad) and reason.tolist() == [5] * len(bad) and rew.tolist() == [0.0] * len(bad)
+    for s in range(len(bad)):
+        assert np.array_equal(obs[s], init_obs) and mask_ids(mask[s]) == init_ids
+    # without auto-reset the position is left as it was
+    env2 = make_env(len(bad), 500)
+    env2.reset()
+    env2.step(np.full(len(bad), init_ids[0], np.int64), auto_reset=False, check_prev=True)
+    obs, mask, nl, rew, done, reason, winner = env2.step(np.asarray(bad, np.int64), auto_reset=False, check_prev=True)
+    assert reason.tolist() == [5] * len(bad)
+    assert np.array_equal(obs, before_obs) and np.array_equal(mask, before_mask)
+    # and the game can continue with a legal move afterwards
+    ids = mask_ids(mask[0])
+    obs, mask, nl, rew, done, reason, winner = env2.step(np.full(len(bad), ids[0], np.int64), auto_reset=False, check_prev=True)
+    assert reason.tolist() == [0] * len(bad) and done.tolist() == [0] * len(bad)

@@ -43,3 +43,17 @@ def test_emu_obs_rows_at_every_alignment_phase():
     from tests.emu.emu import EmuEnv
     for off in (1, 2, 3):
         envcheck.check_random_vs_oracle(lambda n, mm, off=off: EmuEnv(n, mm, obs_offset=off), n_games=5, n_steps=30, seed=off)
+
+
+def test_emu_illegal_actions_rejected():
+    envcheck.check_illegal_actions(make_env)
+
+
+def test_emu_packed_only_masks_random_vs_oracle():
+    """byte-mask pointer NULL: the kernel writes only the 1 696-byte packed mask and validates actions against packed bits"""
+    def mk(n, mm):
+        e = EmuEnv(n, mm)
+        e.packed_only = True
+        return e
+    envcheck.check_random_vs_oracle(mk, n_games=9, n_steps=60, seed=4, drop_bias=0.4)
+    envcheck.check_illegal_actions(mk)

@@ -43,3 +43,20 @@ def test_emu_sample_bf16():
 
 def test_emu_sample_distribution():
     ppocheck.check_sample_distribution(ops, n_draws=2000)
+
+
+def test_emu_packed_masks_give_identical_results():
+    """the kernels fed bit-packed masks produce exactly what they produce from byte masks"""
+    import numpy as np
+    p = EmuOps()
+    p.packed = True
+    ppocheck.check_loss_golden(p)
+    ppocheck.check_sample_golden(p)
+    logits, mask, actions, old_logp, adv, ret, values, old_values = ppocheck.random_loss_inputs(6, 99, dense_rows=1, empty_rows=1)
+    a = ops.ppo_loss(logits, mask, actions, old_logp, adv, ret, values, old_values, 0.2, 0.5, 0.01, 0)
+    b = p.ppo_loss(logits, mask, actions, old_logp, adv, ret, values, old_values, 0.2, 0.5, 0.01, 0)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    (a1, lp1), (a2, lp2) = ops.masked_sample(logits, mask, 5, 6, False), p.masked_sample(logits, mask, 5, 6, False)
+    assert np.array_equal(a1, a2)                       # Gumbel-max is order independent: identical actions
+    np.testing.assert_allclose(lp1, lp2, atol=1e-6)     # the soft-max sum is accumulated in a different order

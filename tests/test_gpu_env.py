@@ -100,3 +100,7 @@ def test_gpu_outputs_at_every_alignment_phase():
             o = ora.step(a.cpu().numpy())
             assert np.array_equal(obs.cpu().numpy(), o[0]) and np.array_equal(mask.cpu().numpy().astype(np.uint8), o[1]), (off, k)
         assert float(oflat[:off].abs().sum()) == 0 and float(oflat[off + N * 46 * 81:].abs().sum()) == 0   # no stray writes
+
+
+def test_gpu_illegal_actions_rejected(make_env):
+    envcheck.check_illegal_actions(make_env)
