@@ -68,10 +68,10 @@ def test_gpu_packed_masks_match_byte_masks():
         assert torch.equal(O.unpack_mask(e_p.legal_bits), e_b.legal_mask)
     lg = torch.randn(N, 13527, device="cuda:0")
     outs = []
+    a, lp = O.masked_sample(lg, e_b.legal_mask, 9, 0)        # same inputs for both forms: the loss kernel is then bit-identical
     for mask in (e_b.legal_mask, e_p.legal_bits):
         x = lg.clone().requires_grad_(True)
         v = torch.zeros(N, device="cuda:0", requires_grad=True)
-        a, lp = O.masked_sample(lg, mask, 9, 0)
         loss, stats = O.ppo_loss(x, v, mask, a, lp - 0.1, torch.ones(N, device="cuda:0"), torch.ones(N, device="cuda:0"))
         loss.backward()
         outs.append((stats.clone(), x.grad.clone(), v.grad.clone()))

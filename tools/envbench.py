@@ -11,7 +11,8 @@ from shogidrl_amd.env import DeviceTimer, VecShogiEnv
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-env = VecShogiEnv(N, 500)
+packed = len(sys.argv) > 3 and sys.argv[3] == "packed"
+env = VecShogiEnv(N, 500, packed_masks=packed)
 env.reset()
 logits = torch.zeros(N, 13527, device="cuda:0")
 acts = []
@@ -19,12 +20,12 @@ acts = []
 tm = DeviceTimer()
 tot_env = 0.0
 for t in range(64):
-    a, _ = ops.masked_sample(logits, env.legal_mask, 42, t)
+    a, _ = ops.masked_sample(logits, (env.legal_bits if packed else env.legal_mask), 42, t)
     env.step(a)
 torch.cuda.synchronize()
 t0 = time.time()
 for t in range(steps):
-    a, _ = ops.masked_sample(logits, env.legal_mask, 42, 64 + t)
+    a, _ = ops.masked_sample(logits, (env.legal_bits if packed else env.legal_mask), 42, 64 + t)
     tm.start()
     env.step(a, validate=False)
     tm.stop()
@@ -32,5 +33,6 @@ for t in range(steps):
 torch.cuda.synchronize()
 wall = time.time() - t0
 ms = tot_env / steps
-print("N=%d env kernel %.3f ms/step -> %.1f M env-steps/s ; %.1f GB/s of 28710 B/step; loop wall %.3f ms/step" %
-      (N, ms, N / ms / 1e3, N * 28710 / ms / 1e6, wall / steps * 1e3))
+bytes_per = (14904 + 1696 + 279) if packed else 28710
+print(("packed " if packed else "") + "N=%d env kernel %.3f ms/step -> %.1f M env-steps/s ; %.1f GB/s of the written bytes/step; loop wall %.3f ms/step" %
+      (N, ms, N / ms / 1e3, N * bytes_per / ms / 1e6, wall / steps * 1e3))
