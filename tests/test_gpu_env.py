@@ -104,3 +104,36 @@ def test_gpu_outputs_at_every_alignment_phase():
 
 def test_gpu_illegal_actions_rejected(make_env):
     envcheck.check_illegal_actions(make_env)
+
+
+def test_gpu_step_is_hipgraph_capturable():
+    """include/keisei_hip.h promises that the step path neither allocates nor synchronises: capture
+    {masked sample -> env step} into a hipGraph (torch.cuda.CUDAGraph on ROCm) and replay it against an eager twin."""
+    import torch
+    from shogidrl_amd import ops
+    from shogidrl_amd.env import VecShogiEnv
+    N = 96
+    eager, graphed = VecShogiEnv(N, 80), VecShogiEnv(N, 80)
+    eager.reset()
+    graphed.reset()
+    logits = torch.randn(N, 13527, device="cuda:0")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                       # warm-up on the capture stream
+        a, _ = ops.masked_sample(logits, graphed.legal_mask, 11, 0)
+        graphed.step(a)
+    torch.cuda.current_stream().wait_stream(side)
+    a, _ = ops.masked_sample(logits, eager.legal_mask, 11, 0)
+    eager.step(a)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        a_g, lp_g = ops.masked_sample(logits, graphed.legal_mask, 11, 0)
+        graphed.step(a_g)
+    for k in range(1, 40):
+        g.replay()
+        a, lp = ops.masked_sample(logits, eager.legal_mask, 11, 0)
+        eager.step(a)
+        # capture itself does not execute: the first replay is the eager twin's step k
+        torch.cuda.synchronize()
+        assert torch.equal(a_g, a) and torch.equal(graphed.obs, eager.obs) and torch.equal(graphed.legal_mask, eager.legal_mask), k
+        assert torch.equal(graphed.done, eager.done) and torch.equal(graphed.reward, eager.reward)
