@@ -303,12 +303,20 @@ static int loss_impl(const void *logits, int logits_dtype, const uint8_t *mask, 
     a.dvalues = dvalues;
     a.stats = stats;
     a.partial = reinterpret_cast<float *>(workspace);
-    if (logits_dtype == 0)
+    // sparse wave-per-row kernel first; rows it flags (more legal actions than its list holds) go to the dense kernel
+    a.only_overflow = 1;
+    const dim3 sgrid((B + KSH_LOSS_WPB - 1) / KSH_LOSS_WPB), sblock(64 * KSH_LOSS_WPB);
+    if (logits_dtype == 0) {
+        hipLaunchKernelGGL(ksh_ppo_loss_sparse_kernel<float>, sgrid, sblock, 0, (hipStream_t)stream, a, (const float *)logits,
+                           (float *)dlogits);
         hipLaunchKernelGGL(ksh_ppo_loss_kernel<float>, dim3(B), dim3(KSH_ROW_THREADS), 0, (hipStream_t)stream, a,
                            (const float *)logits, (float *)dlogits);
-    else
+    } else {
+        hipLaunchKernelGGL(ksh_ppo_loss_sparse_kernel<ksh_bf16>, sgrid, sblock, 0, (hipStream_t)stream, a,
+                           (const ksh_bf16 *)logits, (ksh_bf16 *)dlogits);
         hipLaunchKernelGGL(ksh_ppo_loss_kernel<ksh_bf16>, dim3(B), dim3(KSH_ROW_THREADS), 0, (hipStream_t)stream, a,
                            (const ksh_bf16 *)logits, (ksh_bf16 *)dlogits);
+    }
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(ksh_ppo_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());

@@ -391,7 +391,8 @@ struct KshLossArgs {
     int value_clip;
     float *dvalues;
     float *stats;
-    float *partial;  // [B][8]: surrogate, (V-R)^2, (Vc-R)^2, H, old-new logp, clipped flag, -, -
+    float *partial;  // [B][8]: surrogate, (V-R)^2, (Vc-R)^2, H, old-new logp, clipped flag, overflow flag, -
+    int only_overflow;  // dense kernel: process only the rows the sparse kernel flagged (partial[b][6] != 0)
 };
 
 template <typename T>
@@ -400,6 +401,7 @@ ksh_ppo_loss_kernel(KshLossArgs a, const T *__restrict__ logits, T *__restrict__
     __shared__ KshRowLds R;
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
+    if (a.only_overflow && a.partial[(size_t)b * 8 + 6] == 0.0f) return;   // block-uniform: the sparse kernel did this row
     if (a.mask_bits != nullptr) ksh_load_bits(R, a.mask_bits + (size_t)b * KSH_PBITROW, tid);
     else ksh_build_bits(R, a.mask + (size_t)b * KSH_PA, tid);
     const T *row = logits + (size_t)b * KSH_PA;
@@ -517,6 +519,187 @@ ksh_ppo_loss_kernel(KshLossArgs a, const T *__restrict__ logits, T *__restrict__
         const int j = tail0 + tid;
         const bool on = !none && ((R.bits[j >> 5] >> (j & 31)) & 1u);
         ksh_st(drow + j, on ? grad(j, ksh_ld(row + j)) : 0.0f);
+    }
+}
+
+// ---- sparse fast path: one WAVE per row (4 rows per block, no block barrier).  A real position has ~50 legal
+// actions: their ids go to a per-wave LDS list, their logits are gathered once, the three passes run over the list,
+// the gradient row is zero-filled with 16-byte stores and the few non-zero entries are scattered afterwards (behind
+// an s_waitcnt vmcnt(0), so the scatter stores are ordered after the acknowledged zero stores).  Rows with more
+// than KSH_LOSS_CAP legal actions (dense masks in tests) are only flagged here and done by the block kernel above.
+#define KSH_LOSS_WPB 4
+#define KSH_LOSS_CAP 1024
+
+template <typename T>
+__global__ void __launch_bounds__(64 * KSH_LOSS_WPB)
+ksh_ppo_loss_sparse_kernel(KshLossArgs a, const T *__restrict__ logits, T *__restrict__ dlogits) {
+    __shared__ unsigned short s_j[KSH_LOSS_WPB][KSH_LOSS_CAP];
+    __shared__ float s_z[KSH_LOSS_WPB][KSH_LOSS_CAP];
+    __shared__ unsigned int s_n[KSH_LOSS_WPB];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x * KSH_LOSS_WPB + wv;
+    if (b >= a.B) return;  // wave-uniform
+    const T *row = logits + (size_t)b * KSH_PA;
+    T *drow = dlogits + (size_t)b * KSH_PA;
+    if (lane == 0) s_n[wv] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    auto push = [&](int j) {
+        const unsigned slot = atomicAdd(&s_n[wv], 1u);
+        if (slot < KSH_LOSS_CAP) s_j[wv][slot] = (unsigned short)j;
+    };
+    if (a.mask_bits != nullptr) {
+        const uint32_t *brow = a.mask_bits + (size_t)b * KSH_PBITROW;
+        uint32_t wd[7];
+#pragma unroll
+        for (int it = 0; it < 7; it++) {
+            const int i = lane + 64 * it;
+            wd[it] = i < KSH_PBITROW ? brow[i] : 0u;
+        }
+#pragma unroll
+        for (int it = 0; it < 7; it++) {
+            uint32_t v = wd[it];
+            const int j0 = 32 * (lane + 64 * it);
+            while (v) {
+                const int bit = __ffs((int)v) - 1;
+                v &= v - 1u;
+                if (j0 + bit < KSH_PA) push(j0 + bit);
+            }
+        }
+    } else {
+        const uint8_t *mrow = a.mask + (size_t)b * KSH_PA;
+        const size_t maddr = reinterpret_cast<size_t>(mrow);
+        const int mhead = (int)((16 - (maddr & 15)) & 15);
+        const int mfull = (KSH_PA - mhead) >> 4;
+        const int mtail0 = mhead + 16 * mfull;
+        if (lane < mhead && mrow[lane]) push(lane);
+        if (lane < KSH_PA - mtail0 && mrow[mtail0 + lane]) push(mtail0 + lane);
+        for (int half = 0; half < 2; half++) {
+            uint4 ch[7];
+#pragma unroll
+            for (int it = 0; it < 7; it++) {
+                const int c = lane + 64 * (7 * half + it);
+                ch[it] = uint4{0u, 0u, 0u, 0u};
+                if (c < mfull) ch[it] = *reinterpret_cast<const uint4 *>(mrow + mhead + 16 * c);
+            }
+#pragma unroll
+            for (int it = 0; it < 7; it++) {
+                if ((ch[it].x | ch[it].y | ch[it].z | ch[it].w) != 0u) {
+                    const int j0 = mhead + 16 * (lane + 64 * (7 * half + it));
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        uint32_t v = q == 0 ? ch[it].x : (q == 1 ? ch[it].y : (q == 2 ? ch[it].z : ch[it].w));
+                        while (v) {
+                            const int byte = (__ffs((int)v) - 1) >> 3;
+                            v &= ~(0xFFu << (8 * byte));
+                            push(j0 + 4 * q + byte);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int n = (int)s_n[wv];
+    float *part = a.partial + (size_t)b * 8;
+    if (n > KSH_LOSS_CAP) {          // wave-uniform: leave the row to the dense kernel
+        if (lane == 0) part[6] = 1.0f;
+        return;
+    }
+    // gather the legal logits once; pass 1: soft-max statistics
+    float m = -INFINITY, s = 0.0f;
+    for (int e = lane; e < n; e += 64) {
+        const float z = ksh_ld(row + s_j[wv][e]);
+        s_z[wv][e] = z;
+        ksh_ms_merge(m, s, z, 1.0f);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float m2 = __shfl_xor(m, o), s2 = __shfl_xor(s, o);
+        ksh_ms_merge(m, s, m2, s2);
+    }
+    const bool none = n == 0;
+    const float inv_s = none ? 0.0f : 1.0f / s;
+    const int act = (int)a.actions[b];
+    const float invB = 1.0f / (float)a.B;
+    // pass 2
+    float e1 = 0.0f, e2 = 0.0f, ya = 0.0f;
+    for (int e = lane; e < n; e += 64) {
+        const float y = expf(s_z[wv][e] - m) * inv_s;
+        const bool u = (y >= KSH_EPS) && (y <= 1.0f - KSH_EPS);
+        const float l = logf(fminf(fmaxf(y, KSH_EPS), 1.0f - KSH_EPS));
+        e1 += y * l;
+        e2 += u ? y : 0.0f;
+        if ((int)s_j[wv][e] == act) ya = y;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        e1 += __shfl_xor(e1, o);
+        e2 += __shfl_xor(e2, o);
+        ya += __shfl_xor(ya, o);
+    }
+    float new_logp, H;
+    bool ua;
+    if (none) {
+        new_logp = logf(1.0f / (float)KSH_PA);
+        H = -new_logp;
+        ua = false;
+        ya = 1.0f;
+    } else {
+        ua = (ya >= KSH_EPS) && (ya <= 1.0f - KSH_EPS);
+        new_logp = logf(fminf(fmaxf(ya, KSH_EPS), 1.0f - KSH_EPS));
+        H = -e1;
+    }
+    const float old_lp = a.old_logp[b], A = a.adv[b];
+    const float ratio = expf(new_logp - old_lp);
+    const float surr1 = ratio * A;
+    const float surr2 = fminf(fmaxf(ratio, 1.0f - a.clip_eps), 1.0f + a.clip_eps) * A;
+    const float gr = (surr1 <= surr2) ? A : 0.0f;
+    const float pol = (ua && !none) ? (-gr * ratio * invB) : 0.0f;
+    const float ce = a.ent_coef * invB;
+    const float c = ce * (e1 + e2) + pol;
+    if (lane == 0) {
+        const float V = a.values[b], Rt = a.ret[b];
+        part[0] = fminf(surr1, surr2);
+        part[1] = (V - Rt) * (V - Rt);
+        float vc = 0.0f;
+        if (a.value_clip) {
+            const float ov = a.old_values[b];
+            const float Vc = ov + fminf(fmaxf(V - ov, -a.clip_eps), a.clip_eps);
+            vc = (Vc - Rt) * (Vc - Rt);
+        }
+        part[2] = vc;
+        part[3] = H;
+        part[4] = old_lp - new_logp;
+        part[5] = (fabsf(ratio - 1.0f) > a.clip_eps) ? 1.0f : 0.0f;
+        part[6] = 0.0f;
+        part[7] = 0.0f;
+    }
+    // pass 3: gradients of the legal entries (kept in LDS), zero row, scatter
+    for (int e = lane; e < n; e += 64) {
+        const float y = expf(s_z[wv][e] - m) * inv_s;
+        const bool u = (y >= KSH_EPS) && (y <= 1.0f - KSH_EPS);
+        const float l = logf(fminf(fmaxf(y, KSH_EPS), 1.0f - KSH_EPS));
+        float G = ce * (l + (u ? 1.0f : 0.0f));
+        if ((int)s_j[wv][e] == act) G += pol / y;
+        s_z[wv][e] = y * (G - c);
+    }
+    constexpr int V = KshVec<T>::N;
+    const size_t addr = reinterpret_cast<size_t>(drow);
+    const int head = (int)(((16 - (addr & 15)) & 15) / sizeof(T));
+    const int nvec = (KSH_PA - head) / V;
+    const int tail0 = head + nvec * V;
+    if (lane < head) ksh_st(drow + lane, 0.0f);
+    if (lane < KSH_PA - tail0) ksh_st(drow + tail0 + lane, 0.0f);
+    const uint4 zero = {0u, 0u, 0u, 0u};
+    for (int v = lane; v < nvec; v += 64) *reinterpret_cast<uint4 *>(drow + head + v * V) = zero;
+    if (n > 0) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): every zero store of this wave has been acknowledged
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < n; e += 64) ksh_st(drow + s_j[wv][e], s_z[wv][e]);
     }
 }
 

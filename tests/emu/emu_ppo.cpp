@@ -18,6 +18,10 @@ void loss_entry(void *) {
     if (l_dtype == 0) ksh_ppo_loss_kernel<float>(la, (const float *)l_logits, (float *)l_dlogits);
     else ksh_ppo_loss_kernel<ksh_bf16>(la, (const ksh_bf16 *)l_logits, (ksh_bf16 *)l_dlogits);
 }
+void sparse_entry(void *) {
+    if (l_dtype == 0) ksh_ppo_loss_sparse_kernel<float>(la, (const float *)l_logits, (float *)l_dlogits);
+    else ksh_ppo_loss_sparse_kernel<ksh_bf16>(la, (const ksh_bf16 *)l_logits, (ksh_bf16 *)l_dlogits);
+}
 void stats_entry(void *) { ksh_ppo_stats_kernel(la); }
 }  // namespace
 
@@ -39,6 +43,8 @@ void emu_ppo_loss(const void *logits, int dtype, const uint8_t *mask, const uint
     la.old_values = old_values; la.B = B; la.clip_eps = clip_eps; la.vf_coef = vf; la.ent_coef = ent;
     la.value_clip = value_clip; la.dvalues = dvalues; la.stats = stats; la.partial = workspace;
     l_logits = logits; l_dlogits = dlogits; l_dtype = dtype;
+    la.only_overflow = 1;
+    for (int b = 0; b < (B + KSH_LOSS_WPB - 1) / KSH_LOSS_WPB; b++) emu::run_block(sparse_entry, nullptr, b, 64 * KSH_LOSS_WPB);
     for (int b = 0; b < B; b++) emu::run_block(loss_entry, nullptr, b, KSH_ROW_THREADS);
     emu::run_block(stats_entry, nullptr, 0, 256);
 }

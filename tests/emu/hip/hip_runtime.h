@@ -116,3 +116,4 @@ struct bf16 {
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)

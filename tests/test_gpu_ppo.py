@@ -68,15 +68,15 @@ def test_gpu_packed_masks_match_byte_masks():
         assert torch.equal(O.unpack_mask(e_p.legal_bits), e_b.legal_mask)
     lg = torch.randn(N, 13527, device="cuda:0")
     outs = []
-    a, lp = O.masked_sample(lg, e_b.legal_mask, 9, 0)        # same inputs for both forms: the loss kernel is then bit-identical
+    a, lp = O.masked_sample(lg, e_b.legal_mask, 9, 0)        # same inputs for both forms
     for mask in (e_b.legal_mask, e_p.legal_bits):
         x = lg.clone().requires_grad_(True)
         v = torch.zeros(N, device="cuda:0", requires_grad=True)
         loss, stats = O.ppo_loss(x, v, mask, a, lp - 0.1, torch.ones(N, device="cuda:0"), torch.ones(N, device="cuda:0"))
         loss.backward()
         outs.append((stats.clone(), x.grad.clone(), v.grad.clone()))
-    for x, y in zip(*outs):
-        assert torch.equal(x, y)
+    for x, y in zip(*outs):                                   # same legal set, accumulated in a different order
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-7)
     # an illegal action is rejected through the packed previous mask too
     bad = torch.zeros(N, dtype=torch.int64, device="cuda:0")          # id 0 is never legal at these positions' from-square
     legal0 = O.unpack_mask(e_p.legal_bits)[:, 0]
