@@ -3,12 +3,14 @@ env kernel (a VecShogiEnv of one game).  It exists so that Keisei's EnvManager /
 (and evaluation loops) can drive the GPU engine through the familiar calls:
 
     ShogiGame(max_moves_per_game) / seed / reset / get_observation / get_legal_moves / make_move /
-    current_player / move_count / game_over / winner / termination_reason / from_sfen / to_sfen_string
+    current_player / move_count / game_over / winner / termination_reason / from_sfen / to_sfen_string /
+    to_string / move_history, and game_to_kif(game, filename, sente_player_name, gote_player_name)
 
 (keisei/shogi/shogi_game.py:39-54, 56-73, 113-130, 183-218, 283-345, 574-660; SFEN format
-keisei/shogi/shogi_game_io.py:169-379).  Colours / piece types are plain ints (0 = Black, 1 = White;
+keisei/shogi/shogi_game_io.py:169-379, text board :540-583, KIF export :586-733).  Colours / piece types are plain ints (0 = Black, 1 = White;
 0..13 = P,L,N,S,G,B,R,K,+P,+L,+N,+S,+B,+R); moves are the reference's 5-tuples.  Every call synchronises with
 the device -- this is the plumbing path (BASELINE configs[0]), the batched path is VecShogiEnv."""
+import datetime
 import re
 
 import numpy as np
@@ -112,6 +114,90 @@ def state_to_sfen(rec):
     return "%s %s %s %d" % ("/".join(out), "b" if rec[95] == 0 else "w", hands or "-", mc + 1)
 
 
+_TYPE_NAMES = ("PAWN", "LANCE", "KNIGHT", "SILVER", "GOLD", "BISHOP", "ROOK")
+_KIF_HAND = ((6, "HI"), (5, "KA"), (4, "KI"), (3, "GI"), (2, "KE"), (1, "KY"), (0, "FU"))   # shogi_game_io.py:633-641
+_KIF_TERMINATION = {"Tsumi": "詰み", "Toryo": "投了", "Sennichite": "千日手", "Stalemate": "持将棋",
+                    "Max moves reached": "持将棋"}                                              # shogi_game_io.py:690-697
+_KIF_DRAW_REASONS = ("Sennichite", "impasse", "Max moves reached")                              # shogi_game_io.py:722-726
+
+
+def _symbol(pc):
+    t, color = (pc - 1) % 14, (pc - 1) // 14
+    base = t if t < 8 else {8: 0, 9: 1, 10: 2, 11: 3, 12: 5, 13: 6}[t]
+    ch = _SYM[base] if color == 0 else _SYM[base].lower()
+    return ("+" if t >= 8 else "") + ch
+
+
+def state_to_text(rec):
+    """Text board of a packed state record, character for character the reference's
+    convert_game_to_text_representation (shogi_game_io.py:540-583)."""
+    lines = []
+    for r in range(9):
+        cells = []
+        for c in range(9):
+            pc = int(rec[r * 9 + c])
+            if pc == 0:
+                cells.append(" . ")
+            else:
+                sym = _symbol(pc)
+                cells.append(" %s " % sym if len(sym) == 1 else "%s " % sym)
+        lines.append("%d " % (9 - r) + "".join(cells))
+    lines.append("a b c d e f g h i")
+    mc = int(rec[96]) | (int(rec[97]) << 8)
+    lines.append("Turn: %s, Move: %d" % ("BLACK" if rec[95] == 0 else "WHITE", mc + 1))
+    for color, who in ((0, "Black"), (1, "White")):
+        hand = {_TYPE_NAMES[t]: int(rec[81 + 7 * color + t]) for t in range(7) if rec[81 + 7 * color + t] > 0}
+        lines.append("%s's hand: %s" % (who, hand))
+    return "\n".join(lines)
+
+
+def record_to_kif(rec, moves, sente_player_name="Sente", gote_player_name="Gote", date=None):
+    """KIF text of a game: `rec` = its current packed state record, `moves` = the 5-tuples played so far.
+    Reproduces the reference's game_to_kif (shogi_game_io.py:586-733) including its quirks: the board block is
+    always the HIRATE start, the hand lines and the side-to-move line describe the CURRENT position, drop moves
+    are skipped (their tuple starts with None, :664-671) while the move numbers keep counting, and a stalemate
+    prints its reason but no RESULT line."""
+    date = date or datetime.date.today().strftime("%Y/%m/%d")
+    lines = ["#KIF version=2.0 encoding=UTF-8", "*Event: Casual Game", "*Site: Local Machine", "*Date: %s" % date,
+             "*Player Sente: %s" % sente_player_name, "*Player Gote: %s" % gote_player_name, "*Handicap: HIRATE",
+             "P1-KY-KE-GI-KI-OU-KI-GI-KE-KY", "P2 * -HI * * * * * -KA * ", "P3-FU-FU-FU-FU-FU-FU-FU-FU-FU",
+             "P4 * * * * * * * * * ", "P5 * * * * * * * * * ", "P6 * * * * * * * * * ",
+             "P7+FU+FU+FU+FU+FU+FU+FU+FU+FU", "P8 * +KA * * * * * +HI * ", "P9+KY+KE+GI+KI+OU+KI+GI+KE+KY"]
+    lines.append("P+" + "".join("%02d%s" % (int(rec[81 + t]), sym) for t, sym in _KIF_HAND))
+    lines.append("P-" + "".join("%02d%s" % (int(rec[88 + t]), sym) for t, sym in _KIF_HAND))
+    lines.append("+" if rec[95] == 0 else "-")
+    lines.append("moves")
+    for i, mv in enumerate(moves):
+        if not mv or mv[0] is None or mv[1] is None or mv[2] is None or mv[3] is None:
+            continue
+        lines.append("%d %d%s%d%s%s" % (i + 1, mv[0] + 1, chr(mv[1] + ord("a")), mv[2] + 1, chr(mv[3] + ord("a")),
+                                        "+" if mv[4] else ""))
+    if rec[98]:
+        reason = REASON_NAMES[int(rec[99])]
+        shown = _KIF_TERMINATION.get(reason, reason)
+        if shown:
+            lines.append(shown)
+        w = int(rec[100]) - 1
+        if w == 0:
+            lines.append("RESULT:SENTE_WIN")
+        elif w == 1:
+            lines.append("RESULT:GOTE_WIN")
+        elif reason in _KIF_DRAW_REASONS:
+            lines.append("RESULT:DRAW")
+    lines.append("*EOF")
+    return "\n".join(lines)
+
+
+def game_to_kif(game, filename=None, sente_player_name="Sente", gote_player_name="Gote"):
+    """Reference signature (shogi_game_io.py:586-591): returns the KIF string, or writes `filename` and returns None."""
+    text = record_to_kif(game._rec(), [h["move"] for h in game.move_history], sente_player_name, gote_player_name)
+    if filename:
+        with open(filename, "w", encoding="utf-8") as f:
+            f.write(text)
+        return None
+    return text
+
+
 class ShogiGame:
     def __init__(self, max_moves_per_game=500, device="cuda:0"):
         self._env = VecShogiEnv(1, max_moves_per_game, device=device, auto_reset=False)
@@ -130,12 +216,14 @@ class ShogiGame:
 
     def reset(self):
         self._env.reset()
+        self.move_history = []             # [{"move": 5-tuple}], the part of the reference's entries KIF export reads
         return self.get_observation()
 
     @classmethod
     def from_sfen(cls, sfen_str, max_moves_for_game_instance=500, device="cuda:0"):
         g = cls(max_moves_for_game_instance, device)
         g._env.set_state(0, parse_sfen(sfen_str))
+        g.move_history = []
         g._env.evaluate_termination()      # the reference evaluates termination for the loaded position (shogi_game.py:343)
         return g
 
@@ -190,6 +278,8 @@ class ShogiGame:
         reason = int(self._env.reason.item())
         if reason == 5:
             raise ValueError("Illegal move %r for the current position" % (move_tuple,))
+        if not was_over:
+            self.move_history.append({"move": tuple(move_tuple)})
         done = bool(self._env.done.item())
         info = {"reason": REASON_NAMES[reason] if done else "Game ongoing"}
         w = int(self._env.winner.item())
@@ -201,3 +291,6 @@ class ShogiGame:
         return state_to_sfen(self._rec())
 
     to_sfen = to_sfen_string
+
+    def to_string(self):
+        return state_to_text(self._rec())

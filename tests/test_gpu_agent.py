@@ -171,6 +171,31 @@ def test_single_game_facade_matches_positions_fixture():
     assert n > 100
 
 
+def test_single_game_facade_kif_and_text_export(tmp_path):
+    """game_to_kif / to_string on the HIP engine against the reference's text for the same games (kif.json)."""
+    import datetime
+    import json
+    from shogidrl_amd.game import ShogiGame, game_to_kif
+    from shogidrl_amd.mapper import PolicyOutputMapper
+    mp = PolicyOutputMapper()
+    today = datetime.date.today().strftime("%Y/%m/%d")
+    cases = {c["name"]: c for c in json.load(open(os.path.join(G, "kif.json"), encoding="utf-8"))}
+    for name in ("random_seed5_max60", "midgame_sfen"):
+        c = cases[name]
+        g = ShogiGame.from_sfen(c["sfen"], c["max_moves"]) if c["sfen"] else ShogiGame(c["max_moves"])
+        for ply in range(len(c["actions"]) + 1):
+            snap = c["snaps"].get(str(ply))
+            if snap is not None:
+                assert g.to_string() == snap["text"] and g.to_sfen_string() == snap["sfen"]
+                assert game_to_kif(g, **snap["kwargs"]) == snap["kif"].replace("{DATE}", today)
+            if ply < len(c["actions"]):
+                g.make_move(mp.policy_index_to_shogi_move(c["actions"][ply]))
+        assert g.game_over == c["game_over"] and len(g.move_history) == len(c["actions"])
+        out = tmp_path / (name + ".kif")
+        assert game_to_kif(g, filename=str(out)) is None
+        assert out.read_text(encoding="utf-8").endswith("*EOF")
+
+
 REASONS = {None: 0, "Game ongoing": 0, "Tsumi": 1, "stalemate": 2, "Max moves reached": 3, "Sennichite": 4}
 
 
