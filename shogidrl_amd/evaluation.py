@@ -68,3 +68,59 @@ def play_games(black, white, num_games, max_moves_per_game=500, device="cuda:0",
         draws=sum(1 for x in w if x < 0),
         reasons={REASON_NAMES[k]: r.count(k) for k in sorted(set(r))},
         avg_game_length=float(length.float().mean()))
+
+
+@dataclass
+class MatchResult:
+    """Agent-centric result of a match (keisei/evaluation/core/evaluation_result.py SummaryStats fields for this
+    path: total_games / agent_wins / opponent_wins / draws / win_rate / avg_game_length)."""
+    games: int
+    agent_wins: int
+    opponent_wins: int
+    draws: int
+    agent_sente_games: int
+    avg_game_length: float
+    reasons: dict
+
+    @property
+    def win_rate(self):
+        return self.agent_wins / max(self.games, 1)
+
+
+def evaluate_match(agent, opponent, num_games, max_moves_per_game=500, device="cuda:0", deterministic=True,
+                   balance_colors=True):
+    """Single-opponent evaluation (keisei/evaluation/strategies/single_opponent.py:170-330): the agent plays Sente in
+    half of the games and Gote in the other half when `balance_colors` (the reference's `play_as_both_colors`), each
+    half as one batched play_games call; winners are mapped back to agent / opponent (tournament.py:181-190)."""
+    n_sente = (num_games + 1) // 2 if balance_colors else num_games
+    halves = [(n_sente, True)] + ([(num_games - n_sente, False)] if num_games - n_sente > 0 else [])
+    wins = losses = draws = 0
+    reasons, length_sum = {}, 0.0
+    for n, agent_is_sente in halves:
+        r = play_games(agent if agent_is_sente else opponent, opponent if agent_is_sente else agent, n,
+                       max_moves_per_game, device, deterministic)
+        wins += r.black_wins if agent_is_sente else r.white_wins
+        losses += r.white_wins if agent_is_sente else r.black_wins
+        draws += r.draws
+        length_sum += r.avg_game_length * n
+        for k, v in r.reasons.items():
+            reasons[k] = reasons.get(k, 0) + v
+    return MatchResult(num_games, wins, losses, draws, n_sente, length_sum / max(num_games, 1), reasons)
+
+
+def tournament(agent, opponents, num_games_per_opponent, **kw):
+    """Round of matches against several opponents (keisei/evaluation/strategies/tournament.py:161-260):
+    `opponents` maps a name to a policy; returns name -> MatchResult plus the aggregate under "__total__"."""
+    out = {name: evaluate_match(agent, opp, num_games_per_opponent, **kw) for name, opp in opponents.items()}
+    tot = MatchResult(0, 0, 0, 0, 0, 0.0, {})
+    for r in out.values():
+        tot.avg_game_length = (tot.avg_game_length * tot.games + r.avg_game_length * r.games) / max(tot.games + r.games, 1)
+        tot.games += r.games
+        tot.agent_wins += r.agent_wins
+        tot.opponent_wins += r.opponent_wins
+        tot.draws += r.draws
+        tot.agent_sente_games += r.agent_sente_games
+        for k, v in r.reasons.items():
+            tot.reasons[k] = tot.reasons.get(k, 0) + v
+    out["__total__"] = tot
+    return out

@@ -210,6 +210,25 @@ def test_batched_evaluation_games_finish_and_agree_with_oracle():
     assert res.reasons.get("Tsumi", 0) == res.black_wins + res.white_wins     # only Tsumi produces a winner
 
 
+def test_match_and_tournament_account_seats_like_the_reference():
+    """evaluate_match = the two seatings of play_games mapped back to agent / opponent; tournament aggregates."""
+    from shogidrl_amd.evaluation import UniformRandomPolicy, evaluate_match, play_games, tournament
+    kw = dict(max_moves_per_game=100, deterministic=False)
+    m = evaluate_match(UniformRandomPolicy(3), UniformRandomPolicy(4), 65, **kw)
+    a, b = UniformRandomPolicy(3), UniformRandomPolicy(4)          # same seeds and call order -> same games
+    first = play_games(a, b, 33, **kw)
+    second = play_games(b, a, 32, **kw)
+    assert (m.games, m.agent_sente_games) == (65, 33)
+    assert m.agent_wins == first.black_wins + second.white_wins
+    assert m.opponent_wins == first.white_wins + second.black_wins
+    assert m.draws == first.draws + second.draws and m.agent_wins + m.opponent_wins + m.draws == 65
+    assert abs(m.avg_game_length - (first.avg_game_length * 33 + second.avg_game_length * 32) / 65) < 1e-4
+    t = tournament(UniformRandomPolicy(5), {"r6": UniformRandomPolicy(6), "r7": UniformRandomPolicy(7)}, 16, **kw)
+    assert set(t) == {"r6", "r7", "__total__"} and t["__total__"].games == 32
+    assert t["__total__"].agent_wins == t["r6"].agent_wins + t["r7"].agent_wins
+    assert sum(t["__total__"].reasons.values()) == 32 and 0.0 <= t["__total__"].win_rate <= 1.0
+
+
 def test_config0_single_game_episode_plumbing():
     """BASELINE configs[0]: one ShogiGame self-play episode with the tiny CNN through the reference-style single-game
     calls (StepManager.execute_step order, step_manager.py:98-348): legal moves -> mask -> select_action -> make_move
