@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--replay", type=int, default=96, help="env launches in the roofline replay")
+    ap.add_argument("--compact", action="store_true",
+                    help="SURVEY 8f4 formats for the whole-job loop: bit-packed masks + bf16 channels-last observations "
+                         "(NOT the reference contract; the default run and the roofline replay keep float32 / byte masks)")
     ap.add_argument("--roofline-only", action="store_true", help="only time the env kernel (quick check)")
     return ap.parse_args()
 
@@ -140,8 +143,9 @@ def main():
     cfg = PPOConfig(ppo_epochs=args.epochs, minibatch_size=args.minibatch, mixed_precision=True, channels_last=True,
                     seed=42 + rank)
     agent = VecPPOAgent(model, cfg, dev)
-    env = VecShogiEnv(args.games, 500, device=dev)
-    buf = VecExperienceBuffer(args.rollout, args.games, cfg.gamma, cfg.lambda_gae, dev)
+    fmt = dict(packed_masks=True, obs_format="bf16_nhwc") if args.compact else {}
+    env = VecShogiEnv(args.games, 500, device=dev, **fmt)
+    buf = VecExperienceBuffer(args.rollout, args.games, cfg.gamma, cfg.lambda_gae, dev, **fmt)
     runner = SelfPlayRunner(env, agent, buf)
 
     def barrier():
@@ -206,7 +210,8 @@ def main():
                             "minibatch %d, Adam" % (args.games, args.depth, args.width, args.rollout, args.epochs, args.minibatch),
                 "games_per_gpu": args.games, "rollout_len": args.rollout, "ppo_epochs": args.epochs,
                 "minibatch_size": args.minibatch, "parallelism": "dp%d (games sharded, flat-gradient all-reduce)" % world,
-                "env_dtype": "u32 bitboards -> f32 obs / u8 mask",
+                "env_dtype": ("u32 bitboards -> bf16 channels-last obs / bit-packed mask (compact, SURVEY 8f4)" if args.compact
+                              else "u32 bitboards -> f32 obs / u8 mask"),
             },
             "selfplay_env_steps_per_s": transitions / (roll_ms * 1e-3),
             "ppo_samples_per_s": transitions * args.epochs / (upd_ms * 1e-3),

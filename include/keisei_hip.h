@@ -66,6 +66,18 @@ int ksh_env_destroy(void *handle);
 int ksh_env_num_games(void *handle);
 int ksh_env_max_moves(void *handle);
 
+/* Observation format of every later call on this handle (SURVEY 8 f4 -- a bandwidth reduction beyond the reference
+ * contract, off by default):
+ *   KSH_OBS_F32_NCHW   float32 [N][46][9][9], ShogiGame.get_observation's layout (shogi_game_io.py:434-539)
+ *   KSH_OBS_BF16_NHWC  bfloat16 [N][9][9][46] (channels last), 7 452 B per game: bit for bit
+ *                      obs.to(bfloat16) in channels_last memory format, i.e. the tensor a bf16-autocast stem
+ *                      convolution (PPOAgent.learn's autocast, core/ppo_agent.py:321-330) reads.  The `obs`
+ *                      arguments below then point at that buffer (still 4-byte aligned). */
+#define KSH_OBS_F32_NCHW 0
+#define KSH_OBS_BF16_NHWC 1
+int ksh_env_set_obs_format(void *handle, int obs_format);
+int ksh_env_obs_format(void *handle);
+
 /* Reset the games whose reset_mask[g] != 0 (all games when reset_mask == NULL) to the initial position
  * and write obs / legal mask / legal-move count of EVERY game (non-reset games are re-observed). */
 int ksh_env_reset(void *handle, const uint8_t *reset_mask /*dev [N] or NULL*/, float *obs /*dev*/,

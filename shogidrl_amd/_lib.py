@@ -16,6 +16,7 @@ _lib = None
 # every symbol include/keisei_hip.h declares (tests check the .so exports each of them)
 SYMBOLS = [
     "ksh_last_error", "ksh_version", "ksh_env_create", "ksh_env_destroy", "ksh_env_num_games", "ksh_env_max_moves",
+    "ksh_env_set_obs_format", "ksh_env_obs_format",
     "ksh_env_reset", "ksh_env_observe", "ksh_env_evaluate_termination", "ksh_env_step", "ksh_env_reset_packed", "ksh_env_step_packed", "ksh_env_set_state", "ksh_env_get_state", "ksh_masked_sample", "ksh_masked_sample_packed", "ksh_ppo_loss_fwd_bwd_packed",
     "ksh_gae_scan", "ksh_ppo_loss_workspace_bytes", "ksh_ppo_loss_fwd_bwd", "ksh_event_create", "ksh_event_record",
     "ksh_event_elapsed_ms", "ksh_event_destroy",
@@ -49,6 +50,8 @@ def lib():
     L.ksh_env_destroy.argtypes = [vp]
     L.ksh_env_num_games.argtypes = [vp]
     L.ksh_env_max_moves.argtypes = [vp]
+    L.ksh_env_set_obs_format.argtypes = [vp, C.c_int]
+    L.ksh_env_obs_format.argtypes = [vp]
     L.ksh_env_reset.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ksh_env_observe.argtypes = [vp, vp, vp, vp, vp]
     L.ksh_env_evaluate_termination.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]

@@ -41,6 +41,14 @@ class PPOConfig:
     seed: int = 42
 
 
+def _gather_obs(obs, idx):
+    """Minibatch rows of the flattened observation store.  Compact observations (bf16, channel dimension innermost) are
+    gathered through their dense [M,9,9,46] view so that the result is again a channels_last tensor, not an NCHW copy."""
+    if obs.dim() == 4 and obs.stride(1) == 1 and obs.shape[1] > 1:
+        return obs.permute(0, 2, 3, 1).index_select(0, idx).permute(0, 3, 1, 2)
+    return obs.index_select(0, idx)
+
+
 class VecPPOAgent:
     def __init__(self, model, config=None, device="cuda:0", group=None, name="PPOAgent"):
         self.config = config or PPOConfig()
@@ -66,6 +74,8 @@ class VecPPOAgent:
 
     # ------------------------------------------------------------------ acting
     def _forward(self, obs):
+        if obs.dtype != torch.float32 and not self.config.mixed_precision:
+            obs = obs.float()                                      # compact bf16 observations into an fp32 model
         if self.config.channels_last:
             obs = obs.contiguous(memory_format=torch.channels_last)
         with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=self.config.mixed_precision):
@@ -125,7 +135,7 @@ class VecPPOAgent:
             perm = torch.from_numpy(indices).to(self.device, non_blocking=True)
             for start in range(0, num, cfg.minibatch_size):
                 idx = perm[start:start + cfg.minibatch_size]
-                logits, values = self._forward(obs.index_select(0, idx))
+                logits, values = self._forward(_gather_obs(obs, idx))
                 loss, stats = ops.ppo_loss(logits, values, masks.index_select(0, idx), actions.index_select(0, idx),
                                            old_logp.index_select(0, idx), adv.index_select(0, idx),
                                            ret.index_select(0, idx), old_values.index_select(0, idx),

@@ -11,6 +11,7 @@ import torch
 
 from . import ops
 from ._lib import MASK_WORDS, NUM_ACTIONS
+from .env import empty_obs
 
 
 class ExperienceBuffer:
@@ -84,13 +85,15 @@ class ExperienceBuffer:
 class VecExperienceBuffer:
     """[T, N] rollout storage; obs / legal_masks have T+1 slots (slot T holds the bootstrap observation)."""
 
-    def __init__(self, horizon, num_games, gamma, lambda_gae, device="cuda:0", packed_masks=False):
-        """packed_masks=True stores the legal masks bit-packed (int32 [T+1,N,424]: 8x less memory and traffic)."""
+    def __init__(self, horizon, num_games, gamma, lambda_gae, device="cuda:0", packed_masks=False, obs_format="f32"):
+        """packed_masks=True stores the legal masks bit-packed (int32 [T+1,N,424]: 8x less memory and traffic);
+        obs_format="bf16_nhwc" stores observations the way an env of that format writes them (half the bytes)."""
         self.T, self.N, self.gamma, self.lambda_gae = horizon, num_games, gamma, lambda_gae
         self.packed_masks = bool(packed_masks)
         self.device = torch.device(device)
         d, T, N = self.device, horizon, num_games
-        self.obs = torch.empty((T + 1, N, 46, 9, 9), dtype=torch.float32, device=d)
+        self.obs_format = obs_format
+        self.obs = empty_obs((T + 1, N), obs_format, d)
         if self.packed_masks:
             self.legal_masks = torch.empty((T + 1, N, MASK_WORDS), dtype=torch.int32, device=d)
         else:

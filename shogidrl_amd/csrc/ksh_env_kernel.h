@@ -490,22 +490,10 @@ __device__ __forceinline__ float ksh_obs_elem(const KshWaveLds &W, int f) {
     if (f < KSH_BOARD_F) return ((W.obsbits[f >> 5] >> (f & 31)) & 1u) ? 1.0f : 0.0f;
     return W.metav[(unsigned)(f - KSH_BOARD_F) / 81u];
 }
-__device__ __forceinline__ void ksh_write_obs(KshWaveLds &W, const KshStepArgs &a, int g, int lane, int mf_idx, float mf_hint) {
+// planes 28-45 as float32 values into W.metav (callers sync afterwards)
+__device__ __forceinline__ void ksh_obs_meta(KshWaveLds &W, const KshStepArgs &a, int lane, int mf_idx, float mf_hint) {
     const uint8_t *st8 = ST8(W);
     const int side = st8[S_SIDE];
-    for (int i = lane; i < 80; i += 64) W.obsbits[i] = 0;
-    wave_lds_sync();
-#pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-        const int s = pass * 64 + lane;
-        if (s < 81 && st8[s] != 0) {
-            const int pc = st8[s];
-            const int col = pc >= 15 ? 1 : 0;
-            const int t = pc - 1 - 14 * col;
-            const int bit = ((col == side ? 0 : 14) + t) * 81 + (side == 0 ? s : 80 - s);   // both r and c mirrored (:468-469)
-            atomicOr(&W.obsbits[bit >> 5], 1u << (bit & 31));
-        }
-    }
     if (lane < 14) {
         // planes 28-34 own hand, 35-41 opponent hand; count/18.0 in double, stored as float32 (:513-527)
         const int cidx = lane < 7 ? side : 1 - side;
@@ -522,6 +510,24 @@ __device__ __forceinline__ void ksh_write_obs(KshWaveLds &W, const KshStepArgs &
     } else if (lane < 20) {
         W.metav[lane] = 0.0f;
     }
+}
+__device__ __forceinline__ void ksh_write_obs(KshWaveLds &W, const KshStepArgs &a, int g, int lane, int mf_idx, float mf_hint) {
+    const uint8_t *st8 = ST8(W);
+    const int side = st8[S_SIDE];
+    for (int i = lane; i < 80; i += 64) W.obsbits[i] = 0;
+    wave_lds_sync();
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const int s = pass * 64 + lane;
+        if (s < 81 && st8[s] != 0) {
+            const int pc = st8[s];
+            const int col = pc >= 15 ? 1 : 0;
+            const int t = pc - 1 - 14 * col;
+            const int bit = ((col == side ? 0 : 14) + t) * 81 + (side == 0 ? s : 80 - s);   // both r and c mirrored (:468-469)
+            atomicOr(&W.obsbits[bit >> 5], 1u << (bit & 31));
+        }
+    }
+    ksh_obs_meta(W, a, lane, mf_idx, mf_hint);
     wave_lds_sync();
     // Row g starts at a 4-byte aligned address (rows are 14 904 B apart, so even when the tensor itself is 16-byte
     // aligned every other row is not): `head` floats are written singly up to the first 16-byte boundary, then
@@ -566,11 +572,78 @@ __device__ __forceinline__ void ksh_write_obs(KshWaveLds &W, const KshStepArgs &
     if (lane < KSH_OBSF - tail0) orow[tail0 + lane] = ksh_obs_elem(W, tail0 + lane);
 }
 
+// Compact observation (not part of the reference contract): the same 46 planes as bfloat16 in
+// channels-last order -- element (pov_sq, ch) at row[pov_sq * 46 + ch], 7 452 B per game instead of 14 904 --
+// which is bit for bit what `obs.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)` holds (round to
+// nearest even of the float32 plane values), i.e. exactly the tensor the bf16-autocast stem convolution consumes.
+// A dword holds channels (2k, 2k+1) of one square (46 is even): for k < 14 it is a one-hot test against the
+// square's plane index, for k >= 14 one of nine precomputed pairs of the constant planes.
+#define KSH_OBS16_DW 1863  // 81 * 46 / 2
+__device__ __forceinline__ uint32_t ksh_obs_bf16(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return (b + 0x7FFFu + ((b >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ uint32_t ksh_obs16_dword(const uint8_t *plane, const uint32_t *pair, int d) {
+    const int sq = (int)((unsigned)d / 23u);
+    const int k = d - 23 * sq;
+    const uint32_t pl = plane[sq];
+    if (k >= 14) return pair[k - 14];
+    return (int)(pl >> 1) == k ? (0x3F80u << ((pl & 1u) * 16u)) : 0u;
+}
+__device__ __forceinline__ void ksh_write_obs16(KshWaveLds &W, const KshStepArgs &a, int g, int lane, int mf_idx, float mf_hint) {
+    const uint8_t *st8 = ST8(W);
+    const int side = st8[S_SIDE];
+    uint8_t *plane = reinterpret_cast<uint8_t *>(W.obsbits);       // [81] plane index of the piece on each POV square, 0xFF = empty
+    uint32_t *pair = W.obsbits + 24;                                // [9] bf16 pairs of planes 28-45
+    if (lane < 24) W.obsbits[lane] = 0xFFFFFFFFu;
+    wave_lds_sync();
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const int s = pass * 64 + lane;
+        if (s < 81 && st8[s] != 0) {
+            const int pc = st8[s];
+            const int col = pc >= 15 ? 1 : 0;
+            const int t = pc - 1 - 14 * col;
+            plane[side == 0 ? s : 80 - s] = (uint8_t)((col == side ? 0 : 14) + t);
+        }
+    }
+    ksh_obs_meta(W, a, lane, mf_idx, mf_hint);
+    wave_lds_sync();
+    if (lane < 9) pair[lane] = ksh_obs_bf16(W.metav[2 * lane]) | (ksh_obs_bf16(W.metav[2 * lane + 1]) << 16);
+    wave_lds_sync();
+    uint32_t *orow = reinterpret_cast<uint32_t *>(a.obs) + (size_t)g * KSH_OBS16_DW;   // rows are 4-byte aligned (7 452 B apart)
+    const int head = (int)(((16 - (reinterpret_cast<size_t>(orow) & 15)) & 15) >> 2);
+    const int nfull = (KSH_OBS16_DW - head) >> 2;   // 465 aligned 16-byte chunks
+#pragma unroll
+    for (int it = 0; it < 8; it++) {                // 8 * 64 >= 465
+        const int c = lane + 64 * it;
+        if (c < nfull) {
+            const int d = head + 4 * c;
+            int sq = (int)((unsigned)d / 23u);
+            int k = d - 23 * sq;
+            uint32_t pl = plane[sq];
+            const uint32_t pl_next = plane[sq + 1];  // sq + 1 <= 81: still inside obsbits
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                w[j] = k >= 14 ? pair[k - 14] : ((int)(pl >> 1) == k ? (0x3F80u << ((pl & 1u) * 16u)) : 0u);
+                k++;
+                if (k == 23) { k = 0; pl = pl_next; }
+            }
+            ksh_store16(orow + d, uint4{w[0], w[1], w[2], w[3]});
+        }
+    }
+    if (lane < head) orow[lane] = ksh_obs16_dword(plane, pair, lane);
+    const int tail0 = head + 4 * nfull;
+    if (lane < KSH_OBS16_DW - tail0) orow[tail0 + lane] = ksh_obs16_dword(plane, pair, tail0 + lane);
+}
+
 // Order of one step, chosen around two hardware facts: (1) the kernel is HBM-write bound, so the first
 // observation store must leave as early as possible -- everything it does not need (table staging, move
 // generation) comes after it; (2) on gfx9 loads and stores share one in-order vmcnt, so every global LOAD of
 // a wave (state, action, history, tables) is issued AND consumed before its first observation store.
-extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(KshStepArgs a) {
+template <int OBS16>
+__device__ __forceinline__ void ksh_env_step_body(const KshStepArgs &a) {
     __shared__ KshBlockLds L;
 #ifdef KSH_STAMPS
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
@@ -745,7 +818,8 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
                     KSH_STAMP(4);  // history scanned
                     // ---- observation of the post-move state: issued NOW so the stores drain while the tables are
                     // staged and the move generator runs; rewritten below in the rare case the game ends and is reset
-                    ksh_write_obs(W, a, g, lane, mf_idx, mf_hint);
+                    if (OBS16) ksh_write_obs16(W, a, g, lane, mf_idx, mf_hint);
+                    else ksh_write_obs(W, a, g, lane, mf_idx, mf_hint);
                     obs_written = true;
                     KSH_STAMP(5);  // obs stores issued
                 }
@@ -828,7 +902,10 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
     KSH_STAMP(7);  // termination / reset-regen done
 
     // ---- observation, unless it was already issued right after the move
-    if (!obs_written) ksh_write_obs(W, a, g, lane, mf_idx, mf_hint);
+    if (!obs_written) {
+        if (OBS16) ksh_write_obs16(W, a, g, lane, mf_idx, mf_hint);
+        else ksh_write_obs(W, a, g, lane, mf_idx, mf_hint);
+    }
     KSH_STAMP(9);
 
     // ---- packed legal mask (optional): the LDS bit-set as it is, 106 aligned 16-byte stores per game
@@ -890,3 +967,7 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(K
     wave_lds_sync();
     if (lane < 32) reinterpret_cast<uint32_t *>(a.state + (size_t)g * 128)[lane] = W.st32[lane];
 }
+
+// Two entry points over one body: the reference contract (float32 planes, NCHW) and the compact observation format.
+extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(KshStepArgs a) { ksh_env_step_body<0>(a); }
+extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_c16_kernel(KshStepArgs a) { ksh_env_step_body<1>(a); }

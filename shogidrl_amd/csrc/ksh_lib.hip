@@ -33,6 +33,7 @@ struct KshEnv {
     int n;
     int max_moves;
     int hist_cap;
+    int obs_format;  // KSH_OBS_F32_NCHW | KSH_OBS_BF16_NHWC
     uint8_t *state;
     unsigned long long *hist;
     KshTables *tables;
@@ -92,6 +93,14 @@ int ksh_env_destroy(void *handle) {
 int ksh_env_num_games(void *handle) { return handle ? ((KshEnv *)handle)->n : KSH_E_ARG; }
 int ksh_env_max_moves(void *handle) { return handle ? ((KshEnv *)handle)->max_moves : KSH_E_ARG; }
 
+int ksh_env_set_obs_format(void *handle, int obs_format) {
+    if (!handle) return fail_arg("ksh_env_set_obs_format: null handle");
+    if (obs_format != KSH_OBS_F32_NCHW && obs_format != KSH_OBS_BF16_NHWC) return fail_arg("ksh_env_set_obs_format: unknown format");
+    ((KshEnv *)handle)->obs_format = obs_format;
+    return KSH_OK;
+}
+int ksh_env_obs_format(void *handle) { return handle ? ((KshEnv *)handle)->obs_format : KSH_E_ARG; }
+
 static unsigned long long *g_stamps = nullptr;  // diagnostic builds only (ksh_debug_set_stamps)
 
 static int launch_env(KshEnv *e, int mode, const int64_t *actions, const uint8_t *prev_mask, const uint8_t *reset_mask,
@@ -126,7 +135,10 @@ static int launch_env(KshEnv *e, int mode, const int64_t *actions, const uint8_t
     a.auto_reset = auto_reset;
     a.stamps = g_stamps;
     const int blocks = (e->n + KSH_WPB - 1) / KSH_WPB;
-    hipLaunchKernelGGL(ksh_env_step_kernel, dim3(blocks), dim3(64 * KSH_WPB), 0, (hipStream_t)stream, a);
+    if (e->obs_format == KSH_OBS_BF16_NHWC)
+        hipLaunchKernelGGL(ksh_env_step_c16_kernel, dim3(blocks), dim3(64 * KSH_WPB), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(ksh_env_step_kernel, dim3(blocks), dim3(64 * KSH_WPB), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return KSH_OK;
 }

@@ -21,9 +21,34 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+OBS_FORMATS = {"f32": 0, "bf16_nhwc": 1}     # KSH_OBS_F32_NCHW / KSH_OBS_BF16_NHWC (include/keisei_hip.h)
+
+
+def empty_obs(lead, obs_format, device):
+    """Observation storage of shape [*lead, 46, 9, 9] in the memory layout the env kernel writes for `obs_format`:
+    float32 NCHW, or bfloat16 with the channel dimension innermost (each [46,9,9] block is 7 452 contiguous bytes;
+    a [N,46,9,9] slice is a torch channels_last tensor)."""
+    lead = tuple(lead)
+    if obs_format == "f32":
+        return torch.empty(lead + (46, 9, 9), dtype=torch.float32, device=device)
+    k = len(lead)
+    return torch.empty(lead + (9, 9, 46), dtype=torch.bfloat16, device=device).permute(*range(k), k + 2, k, k + 1)
+
+
+def _obs_dense(obs, obs_format):
+    """True when `obs` ([N,46,9,9]) is one dense block in the layout of `obs_format`."""
+    if obs_format == "f32":
+        return obs.dtype == torch.float32 and obs.is_contiguous()
+    return obs.dtype == torch.bfloat16 and obs.dim() == 4 and obs.permute(0, 2, 3, 1).is_contiguous()
+
+
 class VecShogiEnv:
-    def __init__(self, num_games, max_moves_per_game=500, device="cuda:0", auto_reset=True, packed_masks=False):
-        """packed_masks=True: the kernel writes legal masks ONLY in the bit-packed form (`legal_bits`, int32 [N,424],
+    def __init__(self, num_games, max_moves_per_game=500, device="cuda:0", auto_reset=True, packed_masks=False,
+                 obs_format="f32"):
+        """obs_format="bf16_nhwc": observations are written as bfloat16 in channels_last memory format (7 452 B per
+        game instead of 14 904) -- tensors still have shape [N,46,9,9] and equal
+        `obs_f32.to(torch.bfloat16)` bit for bit; see `empty_obs`.
+        packed_masks=True: the kernel writes legal masks ONLY in the bit-packed form (`legal_bits`, int32 [N,424],
         1 696 B instead of 13 527 B per game-step); `legal_mask` is then unavailable, and the sampler /
         loss ops accept the packed tensor directly."""
         self.device = torch.device(device)
@@ -40,7 +65,11 @@ class VecShogiEnv:
             check(self._L.ksh_env_create(idx, self.num_games, self.max_moves_per_game, _lib.C.byref(h)), "ksh_env_create")
         self._h = h
         n, dev = self.num_games, self.device
-        self.obs = torch.empty((n, 46, 9, 9), dtype=torch.float32, device=dev)
+        if obs_format not in OBS_FORMATS:
+            raise ValueError("obs_format must be one of %r" % (tuple(OBS_FORMATS),))
+        self.obs_format = obs_format
+        check(self._L.ksh_env_set_obs_format(self._h, OBS_FORMATS[obs_format]), "ksh_env_set_obs_format")
+        self.obs = empty_obs((n,), obs_format, dev)
         self.packed_masks = bool(packed_masks)
         self.legal_mask = None if self.packed_masks else torch.empty((n, NUM_ACTIONS), dtype=torch.bool, device=dev)
         self.legal_bits = torch.empty((n, MASK_WORDS), dtype=torch.int32, device=dev) if self.packed_masks else None
@@ -73,6 +102,8 @@ class VecShogiEnv:
         if reset_mask is not None:
             rm = reset_mask.to(device=self.device, dtype=torch.uint8).contiguous()
         if out_obs is not None:
+            if not _obs_dense(out_obs, self.obs_format):
+                raise ValueError("out_obs must be dense in the env's obs format")
             self.obs = out_obs
         if self.packed_masks:
             if out_mask is not None:
@@ -116,8 +147,8 @@ class VecShogiEnv:
         obs = self.obs if out_obs is None else out_obs
         if self.packed_masks:
             bits = self.legal_bits if out_mask is None else out_mask
-            if not obs.is_contiguous() or not bits.is_contiguous() or bits.dtype != torch.int32:
-                raise ValueError("out_obs / out_mask must be contiguous (packed masks: int32 [N,424])")
+            if not _obs_dense(obs, self.obs_format) or not bits.is_contiguous() or bits.dtype != torch.int32:
+                raise ValueError("out_obs / out_mask must be dense in the env's formats (packed masks: int32 [N,424])")
             prev = (self.legal_bits if prev_mask is None else prev_mask).data_ptr() if validate else None
             check(self._L.ksh_env_step_packed(self._h, actions.data_ptr(), prev, obs.data_ptr(), None, bits.data_ptr(),
                                               self.n_legal.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(),
@@ -126,8 +157,8 @@ class VecShogiEnv:
             self.obs, self.legal_bits = obs, bits
             return obs, self.reward, self.done, {"reason": self.reason, "winner": self.winner, "n_legal": self.n_legal}
         mask = self.legal_mask if out_mask is None else out_mask
-        if not obs.is_contiguous() or not mask.is_contiguous():
-            raise ValueError("out_obs / out_mask must be contiguous")
+        if not _obs_dense(obs, self.obs_format) or not mask.is_contiguous():
+            raise ValueError("out_obs / out_mask must be dense in the env's obs format")
         prev = None
         if validate:
             prev = (self.legal_mask if prev_mask is None else prev_mask).data_ptr()

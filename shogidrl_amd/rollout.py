@@ -12,6 +12,7 @@ import torch
 class SelfPlayRunner:
     def __init__(self, env, agent, buffer):
         assert env.num_games == buffer.N and env.packed_masks == buffer.packed_masks
+        assert env.obs_format == getattr(buffer, "obs_format", "f32")
         self.env, self.agent, self.buffer = env, agent, buffer
         self.global_timestep = 0
         self.episodes = torch.zeros(4, dtype=torch.int64, device=env.device)   # episodes, black wins, white wins, draws

@@ -12,7 +12,7 @@ A = 13527
 def _lib():
     subprocess.check_call(["make", "-C", _DIR, "-s"])
     L = C.CDLL(os.path.join(_DIR, "libksh_emu.so"))
-    L.emu_env_launch.argtypes = [C.c_void_p] * 15 + [C.c_int] * 5
+    L.emu_env_launch.argtypes = [C.c_void_p] * 15 + [C.c_int] * 6
     L.emu_build_tables.argtypes = [C.c_void_p, C.c_int]
     L.emu_finish_record.argtypes = [C.c_void_p, C.c_int]
     L.emu_full_hash.argtypes = [C.c_void_p]
@@ -32,6 +32,10 @@ class EmuEnv:
         # obs_offset (in floats) shifts the output buffer to exercise every 16-byte alignment phase of the rows
         self._obs_store = np.zeros(n * 46 * 81 + 8, np.float32)
         self.obs = self._obs_store[obs_offset:obs_offset + n * 46 * 81].reshape(n, 46, 9, 9)
+        # compact format (bf16, channels last): raw bf16 bit patterns [n, 81, 46]; obs_offset then counts dwords
+        self.obs16 = False
+        self._obs16_store = np.zeros(n * 81 * 46 + 16, np.uint16)
+        self.obs16_bits = self._obs16_store[2 * obs_offset:2 * obs_offset + n * 81 * 46].reshape(n, 81, 46)
         self.mask = np.zeros((n, A), np.uint8)
         self.bits = np.zeros((n, 424), np.uint32)
         self.packed_only = False        # True: the kernel writes ONLY the packed mask (byte mask pointer NULL)
@@ -44,6 +48,7 @@ class EmuEnv:
     def _launch(self, mode, actions=None, prev_mask=None, reset_mask=None, auto_reset=1):
         p = lambda x: None if x is None else x.ctypes.data
         self.obs[:] = -7.0          # poison: every byte must be rewritten
+        self._obs16_store[:] = 0x7FC1   # (a NaN pattern the kernel never produces)
         self.mask[:] = 0xCC
         self.bits[:] = 0xDEADBEEF
         prev_bits = None
@@ -52,8 +57,16 @@ class EmuEnv:
                                                          bitorder="little").view(np.uint32))
             prev_mask = None
         self.L.emu_env_launch(p(self.state), p(self.hist), p(self.tables), p(actions), p(prev_mask), p(prev_bits), p(reset_mask),
-                              p(self.obs), None if self.packed_only else p(self.mask), p(self.bits), p(self.n_legal), p(self.reward), p(self.done),
-                              p(self.reason), p(self.winner), self.n, self.max_moves, self.cap, mode, auto_reset)
+                              p(self.obs16_bits) if self.obs16 else p(self.obs), None if self.packed_only else p(self.mask), p(self.bits), p(self.n_legal), p(self.reward), p(self.done),
+                              p(self.reason), p(self.winner), self.n, self.max_moves, self.cap, mode, auto_reset,
+                              1 if self.obs16 else 0)
+        if self.obs16:
+            # nothing outside the rows may be touched, and the float view used by the shared checks is the exact upcast
+            lo = self.obs16_bits.__array_interface__["data"][0] - self._obs16_store.__array_interface__["data"][0]
+            outside = np.ones(self._obs16_store.size, bool)
+            outside[lo // 2:lo // 2 + self.obs16_bits.size] = False
+            assert (self._obs16_store[outside] == 0x7FC1).all(), "compact obs writer stored outside its rows"
+            self.obs[:] = from_bf16_bits(self.obs16_bits).reshape(self.n, 9, 9, 46).transpose(0, 3, 1, 2)
 
     def _sync_masks(self):
         """packed and byte forms must describe the same set; in packed-only mode rebuild the byte view from the bits"""

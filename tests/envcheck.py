@@ -157,7 +157,10 @@ def check_random_vs_oracle(make_env, n_games, n_steps, seed, max_moves=500, drop
     ora = ko.VecGames(n_games, max_moves)
     obs, mask, nl = env.reset()
     o_obs, o_mask, o_nl = ora.observe()
-    assert np.array_equal(obs, o_obs) and np.array_equal(mask, o_mask) and np.array_equal(nl, o_nl)
+    # a backend in the compact observation format reports the exact upcast of its bf16 planes: the oracle's float32
+    # planes are rounded the same way (round to nearest even) before the bit-exact comparison
+    obs_round = getattr(env, "obs_round", None) or (lambda x: x)
+    assert np.array_equal(obs, obs_round(o_obs)) and np.array_equal(mask, o_mask) and np.array_equal(nl, o_nl)
     rng = np.random.default_rng(seed)
     ndone = 0
     for k in range(n_steps):
@@ -171,6 +174,7 @@ def check_random_vs_oracle(make_env, n_games, n_steps, seed, max_moves=500, drop
             acts[s] = int(ids[rng.integers(len(ids))])
         obs, mask, nl, rew, done, reason, winner = env.step(acts, auto_reset=True, check_prev=True)
         o = ora.step(acts, auto_reset=True)
+        o = (obs_round(o[0]),) + tuple(o[1:])
         names = ["obs", "mask", "n_legal", "reward", "done", "reason", "winner"]
         for name, x, y in zip(names, (obs, mask, nl, rew, done, reason, winner), o):
             if not np.array_equal(x, y):

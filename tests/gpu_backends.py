@@ -10,14 +10,18 @@ DEV = "cuda:0"
 
 
 class GpuEnv:
-    def __init__(self, n, max_moves):
+    def __init__(self, n, max_moves, obs_format="f32"):
         self.n = n
-        self.env = VecShogiEnv(n, max_moves, device=DEV)
+        self.env = VecShogiEnv(n, max_moves, device=DEV, obs_format=obs_format)
+        if obs_format != "f32":
+            # compact observations are compared as their exact float32 upcast against the oracle's planes rounded by
+            # torch's own float32 -> bfloat16 conversion (tests/envcheck.py check_random_vs_oracle)
+            self.obs_round = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(torch.bfloat16).float().numpy()
 
     def _out(self):
         e = self.env
         torch.cuda.synchronize()
-        return e.obs.cpu().numpy().copy(), e.legal_mask.cpu().numpy().astype(np.uint8), e.n_legal.cpu().numpy().copy()
+        return np.ascontiguousarray(e.obs.float().cpu().numpy()), e.legal_mask.cpu().numpy().astype(np.uint8), e.n_legal.cpu().numpy().copy()
 
     def reset(self, reset_mask=None):
         rm = None if reset_mask is None else torch.as_tensor(np.asarray(reset_mask, np.uint8), device=DEV)

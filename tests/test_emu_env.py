@@ -57,3 +57,21 @@ def test_emu_packed_only_masks_random_vs_oracle():
         return e
     envcheck.check_random_vs_oracle(mk, n_games=9, n_steps=60, seed=4, drop_bias=0.4)
     envcheck.check_illegal_actions(mk)
+
+
+def test_emu_compact_bf16_channels_last_obs_vs_oracle():
+    """observation planes written as bfloat16, channels last -- bit-exact round-to-nearest-even of the
+    oracle's float32 planes, at every 16-byte alignment phase of the 7 452-byte rows, nothing stored outside them."""
+    from tests.emu.emu import from_bf16_bits, to_bf16_bits
+
+    def mk(off):
+        def f(n, mm):
+            e = EmuEnv(n, mm, obs_offset=off)
+            e.obs16 = True
+            e.obs_round = lambda x: from_bf16_bits(to_bf16_bits(x))
+            return e
+        return f
+    ndone = envcheck.check_random_vs_oracle(mk(0), n_games=12, n_steps=120, seed=21, max_moves=60, drop_bias=0.4)
+    assert ndone >= 12
+    for off in (1, 2, 3):
+        envcheck.check_random_vs_oracle(mk(off), n_games=5, n_steps=24, seed=30 + off)

@@ -122,6 +122,39 @@ def test_rollout_runner_matches_oracle_and_learns():
     assert st["black_wins"] + st["white_wins"] + st["draws"] == st["total_episodes_completed"]
 
 
+def test_compact_formats_run_the_same_rollout_and_update():
+    """with packed masks + bf16 channels-last observations the whole loop (rollout, GAE, PPO update) makes
+    the same decisions as with the reference formats: under bf16 autocast the stem convolution reads identical bits
+    either way, so actions, rewards and dones are identical and the learning metrics agree to fp tolerance."""
+    from shogidrl_amd.agent import PPOConfig, VecPPOAgent
+    from shogidrl_amd.buffer import VecExperienceBuffer
+    from shogidrl_amd.env import VecShogiEnv
+    from shogidrl_amd.models import TinyActorCritic
+    from shogidrl_amd.rollout import SelfPlayRunner
+    N, T = 64, 8
+    runs = []
+    for fmt in ({}, dict(packed_masks=True, obs_format="bf16_nhwc")):
+        torch.manual_seed(0)
+        cfg = PPOConfig(ppo_epochs=1, minibatch_size=256, seed=3, mixed_precision=True, channels_last=True)
+        agent = VecPPOAgent(TinyActorCritic(), cfg, DEV)
+        run = SelfPlayRunner(VecShogiEnv(N, 80, device=DEV, **fmt), agent,
+                             VecExperienceBuffer(T, N, cfg.gamma, cfg.lambda_gae, DEV, **fmt))
+        run.collect()
+        buf = run.buffer
+        snap = dict(actions=buf.actions.clone(), rewards=buf.rewards.clone(), dones=buf.dones.clone(),
+                    values=buf.values.clone(), logp=buf.log_probs.clone(), adv=buf.advantages.clone(),
+                    obs=buf.obs[:T].float().contiguous().clone())
+        snap["metrics"] = run.update()
+        runs.append(snap)
+    a, b = runs
+    assert b["obs"].dtype == torch.float32 and torch.equal(b["obs"], a["obs"].to(torch.bfloat16).float())
+    assert torch.equal(a["actions"], b["actions"]) and torch.equal(a["rewards"], b["rewards"]) and torch.equal(a["dones"], b["dones"])
+    assert torch.allclose(a["values"], b["values"], atol=1e-6) and torch.allclose(a["logp"], b["logp"], atol=1e-5)
+    assert torch.allclose(a["adv"], b["adv"], atol=1e-5)
+    for k in ("ppo/policy_loss", "ppo/value_loss", "ppo/entropy", "ppo/kl_divergence_approx", "ppo/clip_fraction"):
+        assert abs(a["metrics"][k] - b["metrics"][k]) < 1e-4, k
+
+
 def test_reference_style_single_game_calls():
     from shogidrl_amd.agent import VecPPOAgent
     from shogidrl_amd.env import VecShogiEnv

@@ -137,3 +137,31 @@ def test_gpu_step_is_hipgraph_capturable():
         torch.cuda.synchronize()
         assert torch.equal(a_g, a) and torch.equal(graphed.obs, eager.obs) and torch.equal(graphed.legal_mask, eager.legal_mask), k
         assert torch.equal(graphed.done, eager.done) and torch.equal(graphed.reward, eager.reward)
+
+
+def test_gpu_compact_bf16_channels_last_obs():
+    """obs_format="bf16_nhwc" -- against the oracle (rounded with torch's float32 -> bfloat16 conversion),
+    and against the float32 env: the compact tensor IS obs.to(bfloat16) in channels_last memory format, so the
+    bf16-autocast stem convolution sees identical bits.  Rows are 7 452 B apart, so four consecutive games cover all
+    four 16-byte alignment phases."""
+    from shogidrl_amd.env import VecShogiEnv
+    from tests.gpu_backends import GpuEnv
+    ndone = envcheck.check_random_vs_oracle(lambda n, mm: GpuEnv(n, mm, "bf16_nhwc"), n_games=24, n_steps=150, seed=8,
+                                            max_moves=60, drop_bias=0.4)
+    assert ndone >= 24
+    n = 1024
+    e32 = VecShogiEnv(n, 200, obs_format="f32")
+    e16 = VecShogiEnv(n, 200, obs_format="bf16_nhwc")
+    o32, m32 = e32.reset()
+    o16, m16 = e16.reset()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for _ in range(120):
+        assert o16.dtype == torch.bfloat16 and o16.shape == (n, 46, 9, 9)
+        assert o16.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(o16, o32.to(torch.bfloat16)) and torch.equal(m16, m32)
+        a = torch.multinomial(m32.float(), 1, generator=g).squeeze(1)
+        o32, *_ = e32.step(a)
+        o16, *_ = e16.step(a)
+        m32, m16 = e32.legal_mask, e16.legal_mask
+    with pytest.raises(ValueError):
+        e16.step(a, out_obs=torch.empty((n, 46, 9, 9), dtype=torch.bfloat16, device="cuda"))   # NCHW block: wrong layout

@@ -11,8 +11,10 @@ from shogidrl_amd.env import DeviceTimer, VecShogiEnv
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-packed = len(sys.argv) > 3 and sys.argv[3] == "packed"
-env = VecShogiEnv(N, 500, packed_masks=packed)
+variant = sys.argv[3] if len(sys.argv) > 3 else ""        # "", "packed", "obs16", "compact" (= packed + obs16)
+packed = variant in ("packed", "compact")
+obs16 = variant in ("obs16", "compact")
+env = VecShogiEnv(N, 500, packed_masks=packed, obs_format="bf16_nhwc" if obs16 else "f32")
 env.reset()
 logits = torch.zeros(N, 13527, device="cuda:0")
 acts = []
@@ -33,6 +35,6 @@ for t in range(steps):
 torch.cuda.synchronize()
 wall = time.time() - t0
 ms = tot_env / steps
-bytes_per = (14904 + 1696 + 279) if packed else 28710
-print(("packed " if packed else "") + "N=%d env kernel %.3f ms/step -> %.1f M env-steps/s ; %.1f GB/s of the written bytes/step; loop wall %.3f ms/step" %
+bytes_per = (7452 if obs16 else 14904) + (1696 if packed else 13527) + 279
+print((variant + " " if variant else "") + "N=%d env kernel %.3f ms/step -> %.1f M env-steps/s ; %.1f GB/s of the written bytes/step; loop wall %.3f ms/step" %
       (N, ms, N / ms / 1e3, N * bytes_per / ms / 1e6, wall / steps * 1e3))
