@@ -144,6 +144,7 @@ def test_gpu_compact_bf16_channels_last_obs():
     and against the float32 env: the compact tensor IS obs.to(bfloat16) in channels_last memory format, so the
     bf16-autocast stem convolution sees identical bits.  Rows are 7 452 B apart, so four consecutive games cover all
     four 16-byte alignment phases."""
+    import torch
     from shogidrl_amd.env import VecShogiEnv
     from tests.gpu_backends import GpuEnv
     ndone = envcheck.check_random_vs_oracle(lambda n, mm: GpuEnv(n, mm, "bf16_nhwc"), n_games=24, n_steps=150, seed=8,
