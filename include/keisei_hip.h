@@ -176,6 +176,44 @@ int ksh_ppo_loss_fwd_bwd(const void *logits /*dev [B,A]*/, int logits_dtype, con
                          void *dlogits /*dev [B,A]*/, float *dvalues /*dev [B]*/, float *stats /*dev [8]*/,
                          void *workspace /*dev*/, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Tower glue: the normalisation / activation / residual work between the convolutions of the actor-critic
+ * (training/models/resnet_tower.py:28-46 ResidualBlock.forward, :15-26 SqueezeExcitation.forward, :82-83 stem),
+ * fused; the convolutions and linear layers themselves stay in PyTorch-ROCm.  Activations are channels-last:
+ * dense [M][C] matrices, M = N*H*W, dtype 0 = float32 / 1 = bfloat16, 16-byte aligned, C % 8 == 0 and
+ * 256 % (C/8) == 0.  Per-channel parameters and statistics are float32.  `workspace`: device scratch of
+ * ksh_tower_workspace_bytes(C) bytes, reusable by consecutive calls on one stream.
+ *
+ * ksh_bn_fwd_train  nn.BatchNorm2d in training mode (+ optional residual add, + optional ReLU):
+ *                   y = [relu](w * (x - mean) / sqrt(var + eps) + b [+ residual]); batch statistics with the
+ *                   biased variance; running_mean / running_var (may be NULL) blended with `momentum`, the
+ *                   running variance from the unbiased estimate; save_mean / save_invstd [C] for the backward.
+ * ksh_bn_fwd_eval   y = [relu]((x - coef[1][c]) * coef[0][c] + coef[2][c] [+ residual]) with caller-computed
+ *                   coefficients (eval mode: coef = {w / sqrt(running_var + eps), running_mean, b}).
+ * ksh_bn_bwd        gradients of ksh_bn_fwd_train: dx, optional dresidual (= dy masked by the ReLU; pass NULL
+ *                   when there was no residual), dweight / dbias [C]; `y` is only read when relu != 0.
+ * ksh_se_pool       pooled[n][c] = mean over the HW positions of x[n] (adaptive_avg_pool2d(x, 1)).
+ * ksh_se_apply      z = relu(x * scale[n][c] + residual)   (x * s; out += x; relu)
+ * ksh_se_bwd_reduce dscale[n][c] = sum over HW of dz * x, dz = dy * (z > 0)
+ * ksh_se_bwd_apply  dx = dz * scale + dpooled / HW, dresidual = dz
+ * ---------------------------------------------------------------------------------------------- */
+uint64_t ksh_tower_workspace_bytes(int C);
+int ksh_bn_fwd_train(const void *x, const void *residual /*or NULL*/, void *y, int dtype, int64_t M, int C,
+                     const float *weight, const float *bias, float *running_mean, float *running_var, float momentum,
+                     float eps, int relu, float *save_mean, float *save_invstd, void *workspace, void *stream);
+int ksh_bn_fwd_eval(const void *x, const void *residual /*or NULL*/, void *y, int dtype, int64_t M, int C,
+                    const float *coef /*dev [3][C]*/, int relu, void *stream);
+int ksh_bn_bwd(const void *dy, const void *x, const void *y, void *dx, void *dresidual /*or NULL*/, int dtype, int64_t M,
+               int C, const float *weight, const float *save_mean, const float *save_invstd, int relu, float *dweight,
+               float *dbias, void *workspace, void *stream);
+int ksh_se_pool(const void *x, int dtype, int N, int HW, int C, float *pooled /*dev [N][C]*/, void *stream);
+int ksh_se_apply(const void *x, const float *scale /*dev [N][C]*/, const void *residual, void *z, int dtype, int N, int HW,
+                 int C, void *stream);
+int ksh_se_bwd_reduce(const void *dy, const void *z, const void *x, int dtype, int N, int HW, int C,
+                      float *dscale /*dev [N][C]*/, void *stream);
+int ksh_se_bwd_apply(const void *dy, const void *z, const float *scale, const float *dpooled /*dev [N][C]*/, void *dx,
+                     void *dresidual, int dtype, int N, int HW, int C, void *stream);
+
 /* hipEvent helpers so that host code without a HIP binding (bench.py) can time launches on the very
  * stream they were issued on.  ksh_event_elapsed_ms synchronises on `stop`. */
 int ksh_event_create(void **event);

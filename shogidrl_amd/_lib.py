@@ -20,6 +20,8 @@ SYMBOLS = [
     "ksh_env_reset", "ksh_env_observe", "ksh_env_evaluate_termination", "ksh_env_step", "ksh_env_reset_packed", "ksh_env_step_packed", "ksh_env_set_state", "ksh_env_get_state", "ksh_masked_sample", "ksh_masked_sample_packed", "ksh_ppo_loss_fwd_bwd_packed",
     "ksh_gae_scan", "ksh_ppo_loss_workspace_bytes", "ksh_ppo_loss_fwd_bwd", "ksh_event_create", "ksh_event_record",
     "ksh_event_elapsed_ms", "ksh_event_destroy",
+    "ksh_tower_workspace_bytes", "ksh_bn_fwd_train", "ksh_bn_fwd_eval", "ksh_bn_bwd", "ksh_se_pool", "ksh_se_apply",
+    "ksh_se_bwd_reduce", "ksh_se_bwd_apply",
 ]
 
 
@@ -67,6 +69,16 @@ def lib():
     L.ksh_ppo_loss_workspace_bytes.restype = u64
     L.ksh_ppo_loss_workspace_bytes.argtypes = [i32]
     L.ksh_ppo_loss_fwd_bwd.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp]
+    i64 = C.c_int64
+    L.ksh_tower_workspace_bytes.restype = u64
+    L.ksh_tower_workspace_bytes.argtypes = [i32]
+    L.ksh_bn_fwd_train.argtypes = [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp]
+    L.ksh_bn_fwd_eval.argtypes = [vp, vp, vp, i32, i64, i32, vp, i32, vp]
+    L.ksh_bn_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp]
+    L.ksh_se_pool.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    L.ksh_se_apply.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.ksh_se_bwd_reduce.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    L.ksh_se_bwd_apply.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.ksh_event_create.argtypes = [C.POINTER(vp)]
     L.ksh_event_record.argtypes = [vp, vp]
     L.ksh_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(f32)]

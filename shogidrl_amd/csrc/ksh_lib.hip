@@ -11,6 +11,7 @@
 #include "../../include/keisei_hip.h"
 #include "ksh_env_kernel.h"
 #include "ksh_ppo_kernels.h"
+#include "ksh_tower_kernels.h"
 
 static thread_local std::string g_err;
 
@@ -338,6 +339,150 @@ static int loss_impl(const void *logits, int logits_dtype, const uint8_t *mask, 
 #ifdef KSH_STAMPS
 int ksh_debug_set_stamps(void *dev_buffer) { g_stamps = (unsigned long long *)dev_buffer; return KSH_OK; }
 #endif
+
+// ---------------------------------------------------------------------------------- tower glue
+// workspace layout (floats): partial [KSH_TW_MAXG][2][C], coef [3][C]
+uint64_t ksh_tower_workspace_bytes(int C) { return C > 0 ? ((uint64_t)KSH_TW_MAXG * 2 + 3) * (uint64_t)C * 4 : 0; }
+
+static int tower_shape_ok(const char *who, int dtype, int64_t M, int C) {
+    if (dtype != 0 && dtype != 1) { g_err = std::string(who) + ": dtype must be 0 (f32) or 1 (bf16)"; return 0; }
+    if (M <= 0 || C <= 0 || (C & 7) != 0 || (KSH_TW_THREADS % (C >> 3)) != 0 || (C >> 3) > KSH_TW_THREADS) {
+        g_err = std::string(who) + ": need M > 0, C % 8 == 0 and 256 % (C/8) == 0";
+        return 0;
+    }
+    return 1;
+}
+static int aligned16(const void *p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+
+extern "C++" {
+template <typename T>
+static void launch_bn_apply(const void *x, const void *res, void *y, const KshRowSplit &sp, const float *coef, int relu,
+                            hipStream_t st) {
+    const T *xp = (const T *)x, *rp = (const T *)res;
+    T *yp = (T *)y;
+    const dim3 g(sp.G), b(KSH_TW_THREADS);
+    if (relu && res) hipLaunchKernelGGL((ksh_bn_apply_kernel<T, 1, 1>), g, b, 0, st, xp, rp, yp, sp, coef);
+    else if (relu) hipLaunchKernelGGL((ksh_bn_apply_kernel<T, 1, 0>), g, b, 0, st, xp, rp, yp, sp, coef);
+    else if (res) hipLaunchKernelGGL((ksh_bn_apply_kernel<T, 0, 1>), g, b, 0, st, xp, rp, yp, sp, coef);
+    else hipLaunchKernelGGL((ksh_bn_apply_kernel<T, 0, 0>), g, b, 0, st, xp, rp, yp, sp, coef);
+}
+}  // extern "C++"
+
+int ksh_bn_fwd_train(const void *x, const void *residual, void *y, int dtype, int64_t M, int C, const float *weight,
+                     const float *bias, float *running_mean, float *running_var, float momentum, float eps, int relu,
+                     float *save_mean, float *save_invstd, void *workspace, void *stream) {
+    if (!tower_shape_ok("ksh_bn_fwd_train", dtype, M, C)) return KSH_E_ARG;
+    if (!x || !y || !save_mean || !save_invstd || !workspace) return fail_arg("ksh_bn_fwd_train: null pointer");
+    if (!aligned16(x) || !aligned16(y) || !aligned16(residual)) return fail_arg("ksh_bn_fwd_train: activations must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    float *partial = (float *)workspace, *coef = partial + (size_t)KSH_TW_MAXG * 2 * C;
+    const KshRowSplit sp = ksh_row_split(M, C, KSH_TW_MAXG);
+    if (dtype == 0) hipLaunchKernelGGL((ksh_bn_stats_kernel<float>), dim3(sp.G), dim3(KSH_TW_THREADS), 0, st, (const float *)x, sp, (const float *)running_mean, partial);
+    else hipLaunchKernelGGL((ksh_bn_stats_kernel<ksh_bf16>), dim3(sp.G), dim3(KSH_TW_THREADS), 0, st, (const ksh_bf16 *)x, sp, (const float *)running_mean, partial);
+    hipLaunchKernelGGL(ksh_bn_finalize_kernel, dim3((C + 31) / 32), dim3(KSH_TW_THREADS), 0, st, (const float *)partial, sp,
+                       (const float *)running_mean, weight, bias, running_mean, running_var, momentum, eps, save_mean,
+                       save_invstd, coef);
+    const KshRowSplit sa = ksh_row_split(M, C, 4 * KSH_TW_MAXG);
+    if (dtype == 0) launch_bn_apply<float>(x, residual, y, sa, coef, relu, st);
+    else launch_bn_apply<ksh_bf16>(x, residual, y, sa, coef, relu, st);
+    HIP_TRY(hipGetLastError());
+    return KSH_OK;
+}
+
+int ksh_bn_fwd_eval(const void *x, const void *residual, void *y, int dtype, int64_t M, int C, const float *coef, int relu,
+                    void *stream) {
+    if (!tower_shape_ok("ksh_bn_fwd_eval", dtype, M, C)) return KSH_E_ARG;
+    if (!x || !y || !coef) return fail_arg("ksh_bn_fwd_eval: null pointer");
+    if (!aligned16(x) || !aligned16(y) || !aligned16(residual)) return fail_arg("ksh_bn_fwd_eval: activations must be 16-byte aligned");
+    const KshRowSplit sa = ksh_row_split(M, C, 4 * KSH_TW_MAXG);
+    if (dtype == 0) launch_bn_apply<float>(x, residual, y, sa, coef, relu, (hipStream_t)stream);
+    else launch_bn_apply<ksh_bf16>(x, residual, y, sa, coef, relu, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return KSH_OK;
+}
+
+extern "C++" {
+template <typename T>
+static void launch_bn_bwd(const void *dy, const void *x, const void *y, void *dx, void *dres, const KshRowSplit &sp,
+                          const KshRowSplit &sa, const float *weight, const float *mean, const float *invstd, int relu,
+                          float *dw, float *db, float *partial, float *coef, hipStream_t st) {
+    const T *gp = (const T *)dy, *xp = (const T *)x, *yp = (const T *)y;
+    T *dxp = (T *)dx, *drp = (T *)dres;
+    const dim3 b(KSH_TW_THREADS);
+    if (relu) hipLaunchKernelGGL((ksh_bn_bwd_reduce_kernel<T, 1>), dim3(sp.G), b, 0, st, gp, xp, yp, sp, mean, partial);
+    else hipLaunchKernelGGL((ksh_bn_bwd_reduce_kernel<T, 0>), dim3(sp.G), b, 0, st, gp, xp, yp, sp, mean, partial);
+    hipLaunchKernelGGL(ksh_bn_bwd_finalize_kernel, dim3((sp.C + 31) / 32), b, 0, st, (const float *)partial, sp, weight, invstd,
+                       dw, db, coef);
+    const dim3 g(sa.G);
+    if (relu && dres) hipLaunchKernelGGL((ksh_bn_bwd_apply_kernel<T, 1, 1>), g, b, 0, st, gp, xp, yp, dxp, drp, sa, mean, (const float *)coef);
+    else if (relu) hipLaunchKernelGGL((ksh_bn_bwd_apply_kernel<T, 1, 0>), g, b, 0, st, gp, xp, yp, dxp, drp, sa, mean, (const float *)coef);
+    else if (dres) hipLaunchKernelGGL((ksh_bn_bwd_apply_kernel<T, 0, 1>), g, b, 0, st, gp, xp, yp, dxp, drp, sa, mean, (const float *)coef);
+    else hipLaunchKernelGGL((ksh_bn_bwd_apply_kernel<T, 0, 0>), g, b, 0, st, gp, xp, yp, dxp, drp, sa, mean, (const float *)coef);
+}
+}  // extern "C++"
+
+int ksh_bn_bwd(const void *dy, const void *x, const void *y, void *dx, void *dres, int dtype, int64_t M, int C,
+               const float *weight, const float *save_mean, const float *save_invstd, int relu, float *dweight,
+               float *dbias, void *workspace, void *stream) {
+    if (!tower_shape_ok("ksh_bn_bwd", dtype, M, C)) return KSH_E_ARG;
+    if (!dy || !x || !dx || !save_mean || !save_invstd || !workspace || (relu && !y)) return fail_arg("ksh_bn_bwd: null pointer");
+    if (!aligned16(dy) || !aligned16(x) || !aligned16(y) || !aligned16(dx) || !aligned16(dres))
+        return fail_arg("ksh_bn_bwd: activations must be 16-byte aligned");
+    float *partial = (float *)workspace, *coef = partial + (size_t)KSH_TW_MAXG * 2 * C;
+    const KshRowSplit sp = ksh_row_split(M, C, KSH_TW_MAXG), sa = ksh_row_split(M, C, 4 * KSH_TW_MAXG);
+    if (dtype == 0) launch_bn_bwd<float>(dy, x, y, dx, dres, sp, sa, weight, save_mean, save_invstd, relu, dweight, dbias, partial, coef, (hipStream_t)stream);
+    else launch_bn_bwd<ksh_bf16>(dy, x, y, dx, dres, sp, sa, weight, save_mean, save_invstd, relu, dweight, dbias, partial, coef, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return KSH_OK;
+}
+
+static int se_args_ok(const char *who, int dtype, int N, int HW, int C) {
+    if (N <= 0 || HW <= 0) { g_err = std::string(who) + ": need N > 0 and HW > 0"; return 0; }
+    return tower_shape_ok(who, dtype, (int64_t)N * HW, C);
+}
+
+int ksh_se_pool(const void *x, int dtype, int N, int HW, int C, float *pooled, void *stream) {
+    if (!se_args_ok("ksh_se_pool", dtype, N, HW, C)) return KSH_E_ARG;
+    if (!x || !pooled || !aligned16(x)) return fail_arg("ksh_se_pool: null or misaligned pointer");
+    if (dtype == 0) hipLaunchKernelGGL((ksh_se_pool_kernel<float>), dim3(N), dim3(KSH_TW_THREADS), 0, (hipStream_t)stream, (const float *)x, HW, C, pooled);
+    else hipLaunchKernelGGL((ksh_se_pool_kernel<ksh_bf16>), dim3(N), dim3(KSH_TW_THREADS), 0, (hipStream_t)stream, (const ksh_bf16 *)x, HW, C, pooled);
+    HIP_TRY(hipGetLastError());
+    return KSH_OK;
+}
+
+int ksh_se_apply(const void *x, const float *scale, const void *residual, void *z, int dtype, int N, int HW, int C,
+                 void *stream) {
+    if (!se_args_ok("ksh_se_apply", dtype, N, HW, C)) return KSH_E_ARG;
+    if (!x || !scale || !residual || !z || !aligned16(x) || !aligned16(residual) || !aligned16(z))
+        return fail_arg("ksh_se_apply: null or misaligned pointer");
+    if (dtype == 0) hipLaunchKernelGGL((ksh_se_apply_kernel<float>), dim3(N), dim3(KSH_TW_THREADS), 0, (hipStream_t)stream, (const float *)x, scale, (const float *)residual, (float *)z, HW, C);
+    else hipLaunchKernelGGL((ksh_se_apply_kernel<ksh_bf16>), dim3(N), dim3(KSH_TW_THREADS), 0, (hipStream_t)stream, (const ksh_bf16 *)x, scale, (const ksh_bf16 *)residual, (ksh_bf16 *)z, HW, C);
+    HIP_TRY(hipGetLastError());
+    return KSH_OK;
+}
+
+int ksh_se_bwd_reduce(const void *dy, const void *z, const void *x, int dtype, int N, int HW, int C, float *dscale,
+                      void *stream) {
+    if (!se_args_ok("ksh_se_bwd_reduce", dtype, N, HW, C)) return KSH_E_ARG;
+    if (!dy || !z || !x || !dscale || !aligned16(dy) || !aligned16(z) || !aligned16(x))
+        return fail_arg("ksh_se_bwd_reduce: null or misaligned pointer");
+    if (dtype == 0) hipLaunchKernelGGL((ksh_se_bwd_reduce_kernel<float>), dim3(N), dim3(KSH_TW_THREADS), 0, (hipStream_t)stream, (const float *)dy, (const float *)z, (const float *)x, HW, C, dscale);
+    else hipLaunchKernelGGL((ksh_se_bwd_reduce_kernel<ksh_bf16>), dim3(N), dim3(KSH_TW_THREADS), 0, (hipStream_t)stream, (const ksh_bf16 *)dy, (const ksh_bf16 *)z, (const ksh_bf16 *)x, HW, C, dscale);
+    HIP_TRY(hipGetLastError());
+    return KSH_OK;
+}
+
+int ksh_se_bwd_apply(const void *dy, const void *z, const float *scale, const float *dpooled, void *dx, void *dresidual,
+                     int dtype, int N, int HW, int C, void *stream) {
+    if (!se_args_ok("ksh_se_bwd_apply", dtype, N, HW, C)) return KSH_E_ARG;
+    if (!dy || !z || !scale || !dpooled || !dx || !dresidual || !aligned16(dy) || !aligned16(z) || !aligned16(dx) ||
+        !aligned16(dresidual))
+        return fail_arg("ksh_se_bwd_apply: null or misaligned pointer");
+    if (dtype == 0) hipLaunchKernelGGL((ksh_se_bwd_apply_kernel<float>), dim3(N), dim3(KSH_TW_THREADS), 0, (hipStream_t)stream, (const float *)dy, (const float *)z, scale, dpooled, (float *)dx, (float *)dresidual, HW, C);
+    else hipLaunchKernelGGL((ksh_se_bwd_apply_kernel<ksh_bf16>), dim3(N), dim3(KSH_TW_THREADS), 0, (hipStream_t)stream, (const ksh_bf16 *)dy, (const ksh_bf16 *)z, scale, dpooled, (ksh_bf16 *)dx, (ksh_bf16 *)dresidual, HW, C);
+    HIP_TRY(hipGetLastError());
+    return KSH_OK;
+}
 
 // ---------------------------------------------------------------------------------- timing helpers
 int ksh_event_create(void **ev) {

@@ -14,12 +14,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "ksh_device_util.h"
+
 #define KSH_PA 13527
 #define KSH_ROW_THREADS 256
 #define KSH_BITW 432
 #define KSH_PBITROW 424   // dwords per row of a packed mask (matches KSH_BITROW of the env kernel)
 
-typedef __bf16 ksh_bf16;
 
 // ------------------------------------------------------------------------------------------ GAE
 // One thread per stream n, sequential in t, coalesced across n.  Every binary op is individually
@@ -50,23 +51,6 @@ extern "C" __global__ void ksh_gae_kernel(const float *__restrict__ r, const flo
         ret[i] = gae + vi;
         next_v = vi;
     }
-}
-
-// ------------------------------------------------------------------------------------------ helpers
-__device__ __forceinline__ float ksh_u2f(uint32_t u) {
-    union { uint32_t u; float f; } c;
-    c.u = u;
-    return c.f;
-}
-__device__ __forceinline__ float ksh_ld(const float *p) { return *p; }
-__device__ __forceinline__ float ksh_ld(const ksh_bf16 *p) {
-    return ksh_u2f((uint32_t)(*reinterpret_cast<const uint16_t *>(p)) << 16);
-}
-__device__ __forceinline__ void ksh_st(float *p, float v) { *p = v; }
-__device__ __forceinline__ void ksh_st(ksh_bf16 *p, float v) { *p = (ksh_bf16)v; }
-__device__ __forceinline__ uint16_t ksh_bf16_bits(float v) {
-    ksh_bf16 b = (ksh_bf16)v;
-    return *reinterpret_cast<uint16_t *>(&b);
 }
 
 struct KshRowLds {

@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import tower
 from ._lib import NUM_ACTIONS
 
 
@@ -25,16 +26,29 @@ class TinyActorCritic(nn.Module):
         return self.policy_head(h), self.value_head(h).squeeze(-1)
 
 
-class _BN(nn.BatchNorm2d):
-    """nn.BatchNorm2d (same parameters / buffers / state-dict keys) evaluated by ATen's native batch-norm kernels
-    instead of MIOpen's: on MI355X with channels_last bf16 activations that is the faster pairing with MIOpen's
-    NHWC implicit-GEMM convolutions (no layout transposes, tower fwd+bwd 83 -> 71 ms at batch 4096)."""
+FUSED_TOWER_GLUE = True      # False: always take the ATen path (tests compare the two)
 
-    def forward(self, x):
+
+class _BN(nn.BatchNorm2d):
+    """nn.BatchNorm2d (same parameters / buffers / state-dict keys) with the following ReLU / residual add folded in:
+    `forward(x, residual=None, relu=False)` = [relu](bn(x) [+ residual]).  Channels-last CUDA activations go through
+    the fused HIP kernels (shogidrl_amd.tower: one statistics pass + one apply pass instead of the framework's
+    statistics / transform / add / relu kernels); everything else (CPU, the 2-plane heads) through ATen's native batch
+    norm -- not MIOpen's, which on MI355X pairs worse with the NHWC implicit-GEMM convolutions."""
+
+    def forward(self, x, residual=None, relu=False):
+        if FUSED_TOWER_GLUE and x.is_cuda:
+            y = tower.bn_act(x, self, residual, relu)
+            if y is not None:
+                return y
         if x.is_cuda:
             with torch.backends.cudnn.flags(enabled=False):
-                return super().forward(x)
-        return super().forward(x)
+                y = super().forward(x)
+        else:
+            y = super().forward(x)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
 
 
 class _SE(nn.Module):
@@ -59,11 +73,12 @@ class _Block(nn.Module):
         self.se = _SE(channels, se_ratio) if se_ratio else None
 
     def forward(self, x):
-        y = F.relu(self.bn1(self.conv1(x)))
+        y = self.bn1(self.conv1(x), relu=True)
+        if self.se is None:
+            return self.bn2(self.conv2(y), residual=x, relu=True)
         y = self.bn2(self.conv2(y))
-        if self.se is not None:
-            y = self.se(y)
-        return F.relu(y + x)
+        z = tower.se_tail(y, self.se, x) if (FUSED_TOWER_GLUE and y.is_cuda) else None
+        return z if z is not None else F.relu(self.se(y) + x)
 
 
 class ResTowerActorCritic(nn.Module):
@@ -81,7 +96,7 @@ class ResTowerActorCritic(nn.Module):
                                         nn.Linear(2 * 81, 1))
 
     def trunk(self, x):
-        return self.res_blocks(F.relu(self.bn_stem(self.stem(x))))
+        return self.res_blocks(self.bn_stem(self.stem(x), relu=True))
 
     def forward(self, x):
         h = self.trunk(x)

@@ -186,3 +186,95 @@ class EmuOps:
                              rt.ctypes.data, vl.ctypes.data, ov.ctypes.data, B, clip_eps, vf, ent, int(value_clip),
                              dl.ctypes.data, dv.ctypes.data, st.ctypes.data, ws.ctypes.data)
         return (from_bf16_bits(dl) if bf16 else dl), dv, st
+
+
+# ------------------------------------------------------------------ tower-glue kernels
+class EmuTower:
+    """numpy backend of tests/towercheck.py over the host-emulated kernels; activations are dense [M, C] float32
+    arrays that are converted to bf16 bit patterns for the bf16 instantiations."""
+
+    def __init__(self):
+        self.L = _lib()
+        vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+        self.L.emu_tower_workspace_floats.restype = i64
+        self.L.emu_tower_workspace_floats.argtypes = [i32]
+        self.L.emu_bn_fwd_train.argtypes = [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp]
+        self.L.emu_bn_fwd_eval.argtypes = [vp, vp, vp, i32, i64, i32, vp, i32]
+        self.L.emu_bn_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, vp, vp, vp, i32, vp, vp, vp]
+        self.L.emu_se_pool.argtypes = [vp, i32, i32, i32, i32, vp]
+        self.L.emu_se_apply.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32]
+        self.L.emu_se_bwd_reduce.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+        self.L.emu_se_bwd_apply.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]
+
+    @staticmethod
+    def _in(a, bf16):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, np.float32)
+        return to_bf16_bits(a).reshape(a.shape) if bf16 else a
+
+    @staticmethod
+    def _out(shape, bf16):
+        return np.full(shape, 0x7FC1, np.uint16) if bf16 else np.full(shape, np.nan, np.float32)
+
+    @staticmethod
+    def _f(a, bf16):
+        return from_bf16_bits(a).reshape(a.shape) if bf16 else a
+
+    def _ws(self, Cn):
+        return np.zeros(self.L.emu_tower_workspace_floats(Cn), np.float32)
+
+    def bn_fwd_train(self, x, res, bf16, w, b, rm, rv, momentum, eps, relu):
+        M, Cn = x.shape
+        p = lambda t: None if t is None else t.ctypes.data
+        xi, ri, y = self._in(x, bf16), self._in(res, bf16), self._out(x.shape, bf16)
+        mean, invstd = np.zeros(Cn, np.float32), np.zeros(Cn, np.float32)
+        ws = self._ws(Cn)
+        self.L.emu_bn_fwd_train(p(xi), p(ri), p(y), int(bf16), M, Cn, p(w), p(b), p(rm), p(rv), momentum, eps, int(relu),
+                                p(mean), p(invstd), p(ws))
+        return self._f(y, bf16), rm, rv, mean, invstd
+
+    def bn_fwd_eval(self, x, res, bf16, coef, relu):
+        M, Cn = x.shape
+        p = lambda t: None if t is None else t.ctypes.data
+        xi, ri, y = self._in(x, bf16), self._in(res, bf16), self._out(x.shape, bf16)
+        coef = np.ascontiguousarray(coef, np.float32)
+        self.L.emu_bn_fwd_eval(p(xi), p(ri), p(y), int(bf16), M, Cn, p(coef), int(relu))
+        return self._f(y, bf16)
+
+    def bn_bwd(self, dy, x, y, bf16, w, mean, invstd, relu, residual):
+        M, Cn = x.shape
+        p = lambda t: None if t is None else t.ctypes.data
+        gi, xi, yi = self._in(dy, bf16), self._in(x, bf16), self._in(y, bf16)
+        dx = self._out(x.shape, bf16)
+        dres = self._out(x.shape, bf16) if (residual and relu) else None
+        dw, db = np.zeros(Cn, np.float32), np.zeros(Cn, np.float32)
+        ws = self._ws(Cn)
+        self.L.emu_bn_bwd(p(gi), p(xi), p(yi), p(dx), p(dres), int(bf16), M, Cn, p(w), p(mean), p(invstd), int(relu), p(dw),
+                          p(db), p(ws))
+        dres_f = None if not residual else (self._f(dres, bf16) if relu else np.asarray(dy, np.float32))
+        return self._f(dx, bf16), dres_f, dw, db
+
+    def se_pool(self, x, bf16, N, HW, Cn):
+        xi, out = self._in(x, bf16), np.zeros((N, Cn), np.float32)
+        self.L.emu_se_pool(xi.ctypes.data, int(bf16), N, HW, Cn, out.ctypes.data)
+        return out
+
+    def se_apply(self, x, s, r, bf16, N, HW, Cn):
+        xi, ri, z = self._in(x, bf16), self._in(r, bf16), self._out(x.shape, bf16)
+        s = np.ascontiguousarray(s, np.float32)
+        self.L.emu_se_apply(xi.ctypes.data, s.ctypes.data, ri.ctypes.data, z.ctypes.data, int(bf16), N, HW, Cn)
+        return self._f(z, bf16)
+
+    def se_bwd_reduce(self, dz, z, x, bf16, N, HW, Cn):
+        gi, zi, xi, ds = self._in(dz, bf16), self._in(z, bf16), self._in(x, bf16), np.zeros((N, Cn), np.float32)
+        self.L.emu_se_bwd_reduce(gi.ctypes.data, zi.ctypes.data, xi.ctypes.data, int(bf16), N, HW, Cn, ds.ctypes.data)
+        return ds
+
+    def se_bwd_apply(self, dz, z, s, dp, bf16, N, HW, Cn):
+        gi, zi = self._in(dz, bf16), self._in(z, bf16)
+        dx, dr = self._out(dz.shape, bf16), self._out(dz.shape, bf16)
+        s, dp = np.ascontiguousarray(s, np.float32), np.ascontiguousarray(dp, np.float32)
+        self.L.emu_se_bwd_apply(gi.ctypes.data, zi.ctypes.data, s.ctypes.data, dp.ctypes.data, dx.ctypes.data, dr.ctypes.data,
+                                int(bf16), N, HW, Cn)
+        return self._f(dx, bf16), self._f(dr, bf16)

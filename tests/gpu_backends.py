@@ -96,3 +96,82 @@ class GpuOps:
                                    t(old_values), clip_eps, vf, ent, bool(value_clip))
         loss.backward()
         return lg.grad.float().cpu().numpy(), vl.grad.cpu().numpy(), stats.cpu().numpy()
+
+
+class GpuTower:
+    """numpy backend of tests/towercheck.py over the C-ABI tower entry points (dense [M, C] activations)."""
+
+    def __init__(self):
+        from shogidrl_amd._lib import check, lib
+        self.L, self.check = lib(), check
+        self.st = lambda: torch.cuda.current_stream().cuda_stream
+
+    @staticmethod
+    def _t(a, bf16=False):
+        if a is None:
+            return None
+        t = torch.as_tensor(np.ascontiguousarray(a, np.float32), device=DEV)
+        return t.to(torch.bfloat16) if bf16 else t
+
+    @staticmethod
+    def _np(t):
+        return t.float().cpu().numpy()
+
+    def _ws(self, C):
+        return torch.empty(self.L.ksh_tower_workspace_bytes(C) // 4, dtype=torch.float32, device=DEV)
+
+    def bn_fwd_train(self, x, res, bf16, w, b, rm, rv, momentum, eps, relu):
+        M, C = x.shape
+        p = lambda t: None if t is None else t.data_ptr()
+        xt, rt = self._t(x, bf16), self._t(res, bf16)
+        y = torch.full_like(xt, float("nan"))
+        wt, bt, rmt, rvt = self._t(w), self._t(b), self._t(rm), self._t(rv)
+        mean, invstd, ws = torch.empty(C, device=DEV), torch.empty(C, device=DEV), self._ws(C)
+        self.check(self.L.ksh_bn_fwd_train(p(xt), p(rt), p(y), int(bf16), M, C, p(wt), p(bt), p(rmt), p(rvt), momentum, eps,
+                                           int(relu), p(mean), p(invstd), p(ws), self.st()), "ksh_bn_fwd_train")
+        return self._np(y), self._np(rmt), self._np(rvt), self._np(mean), self._np(invstd)
+
+    def bn_fwd_eval(self, x, res, bf16, coef, relu):
+        M, C = x.shape
+        p = lambda t: None if t is None else t.data_ptr()
+        xt, rt, ct = self._t(x, bf16), self._t(res, bf16), self._t(coef)
+        y = torch.full_like(xt, float("nan"))
+        self.check(self.L.ksh_bn_fwd_eval(p(xt), p(rt), p(y), int(bf16), M, C, p(ct), int(relu), self.st()), "ksh_bn_fwd_eval")
+        return self._np(y)
+
+    def bn_bwd(self, dy, x, y, bf16, w, mean, invstd, relu, residual):
+        M, C = x.shape
+        p = lambda t: None if t is None else t.data_ptr()
+        gt, xt, yt = self._t(dy, bf16), self._t(x, bf16), self._t(y, bf16)
+        dx = torch.full_like(xt, float("nan"))
+        dres = torch.full_like(xt, float("nan")) if (residual and relu) else None
+        dw, db, ws = torch.empty(C, device=DEV), torch.empty(C, device=DEV), self._ws(C)
+        self.check(self.L.ksh_bn_bwd(p(gt), p(xt), p(yt), p(dx), p(dres), int(bf16), M, C, p(self._t(w)), p(self._t(mean)),
+                                     p(self._t(invstd)), int(relu), p(dw), p(db), p(ws), self.st()), "ksh_bn_bwd")
+        dres_f = None if not residual else (self._np(dres) if relu else np.asarray(dy, np.float32))
+        return self._np(dx), dres_f, self._np(dw), self._np(db)
+
+    def se_pool(self, x, bf16, N, HW, C):
+        xt, out = self._t(x, bf16), torch.empty((N, C), device=DEV)
+        self.check(self.L.ksh_se_pool(xt.data_ptr(), int(bf16), N, HW, C, out.data_ptr(), self.st()), "ksh_se_pool")
+        return self._np(out)
+
+    def se_apply(self, x, s, r, bf16, N, HW, C):
+        xt, rt, st = self._t(x, bf16), self._t(r, bf16), self._t(s)
+        z = torch.full_like(xt, float("nan"))
+        self.check(self.L.ksh_se_apply(xt.data_ptr(), st.data_ptr(), rt.data_ptr(), z.data_ptr(), int(bf16), N, HW, C, self.st()),
+                   "ksh_se_apply")
+        return self._np(z)
+
+    def se_bwd_reduce(self, dz, z, x, bf16, N, HW, C):
+        gt, zt, xt, ds = self._t(dz, bf16), self._t(z, bf16), self._t(x, bf16), torch.empty((N, C), device=DEV)
+        self.check(self.L.ksh_se_bwd_reduce(gt.data_ptr(), zt.data_ptr(), xt.data_ptr(), int(bf16), N, HW, C, ds.data_ptr(),
+                                            self.st()), "ksh_se_bwd_reduce")
+        return self._np(ds)
+
+    def se_bwd_apply(self, dz, z, s, dp, bf16, N, HW, C):
+        gt, zt, st, dpt = self._t(dz, bf16), self._t(z, bf16), self._t(s), self._t(dp)
+        dx, dr = torch.full_like(gt, float("nan")), torch.full_like(gt, float("nan"))
+        self.check(self.L.ksh_se_bwd_apply(gt.data_ptr(), zt.data_ptr(), st.data_ptr(), dpt.data_ptr(), dx.data_ptr(),
+                                           dr.data_ptr(), int(bf16), N, HW, C, self.st()), "ksh_se_bwd_apply")
+        return self._np(dx), self._np(dr)
