@@ -146,8 +146,9 @@ class GpuTower:
         dx = torch.full_like(xt, float("nan"))
         dres = torch.full_like(xt, float("nan")) if (residual and relu) else None
         dw, db, ws = torch.empty(C, device=DEV), torch.empty(C, device=DEV), self._ws(C)
-        self.check(self.L.ksh_bn_bwd(p(gt), p(xt), p(yt), p(dx), p(dres), int(bf16), M, C, p(self._t(w)), p(self._t(mean)),
-                                     p(self._t(invstd)), int(relu), p(dw), p(db), p(ws), self.st()), "ksh_bn_bwd")
+        wt, mt, it = self._t(w), self._t(mean), self._t(invstd)      # keep the tensors alive across the launch
+        self.check(self.L.ksh_bn_bwd(p(gt), p(xt), p(yt), p(dx), p(dres), int(bf16), M, C, p(wt), p(mt), p(it), int(relu),
+                                     p(dw), p(db), p(ws), self.st()), "ksh_bn_bwd")
         dres_f = None if not residual else (self._np(dres) if relu else np.asarray(dy, np.float32))
         return self._np(dx), dres_f, self._np(dw), self._np(db)
 
