@@ -80,7 +80,8 @@ def test_model_with_fused_glue_matches_aten_fp32(se_ratio):
         assert torch.allclose(la, lb, rtol=1e-4, atol=1e-4) and torch.allclose(va, vb, rtol=1e-4, atol=1e-4)
     for k in b[1]:
         scale = b[1][k].abs().max().item() + 1e-6
-        assert (a[1][k] - b[1][k]).abs().max().item() <= 2e-3 * scale, k
+        # (+1e-6: biases of convolutions that feed a BatchNorm have a true gradient of zero -- both sides are noise)
+        assert (a[1][k] - b[1][k]).abs().max().item() <= 2e-3 * scale + 1e-6, k
     for k in b[2]:
         assert torch.allclose(a[2][k], b[2][k], rtol=1e-4, atol=1e-5), k           # running stats, num_batches_tracked
     assert torch.allclose(a[3], b[3], rtol=1e-4, atol=1e-4)                        # eval-mode forward
@@ -93,6 +94,6 @@ def test_model_with_fused_glue_matches_aten_bf16_autocast():
         assert (la - lb).abs().max().item() <= 0.05 * (lb.abs().max().item() + 1e-3)
     for k in b[1]:
         scale = b[1][k].abs().max().item() + 1e-6
-        assert (a[1][k] - b[1][k]).abs().max().item() <= 0.08 * scale, k
+        assert (a[1][k] - b[1][k]).abs().max().item() <= 0.08 * scale + 1e-4, k
     for k in b[2]:
         assert torch.allclose(a[2][k], b[2][k], rtol=2e-2, atol=2e-3), k
