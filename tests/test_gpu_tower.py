@@ -87,13 +87,23 @@ def test_model_with_fused_glue_matches_aten_fp32(se_ratio):
     assert torch.allclose(a[3], b[3], rtol=1e-4, atol=1e-4)                        # eval-mode forward
 
 
-def test_model_with_fused_glue_matches_aten_bf16_autocast():
-    a = _run_model(True, True, 0.25)
-    b = _run_model(False, True, 0.25)
-    for (la, va), (lb, vb) in zip(a[0], b[0]):
-        assert (la - lb).abs().max().item() <= 0.05 * (lb.abs().max().item() + 1e-3)
-    for k in b[1]:
-        scale = b[1][k].abs().max().item() + 1e-6
-        assert (a[1][k] - b[1][k]).abs().max().item() <= 0.08 * scale + 1e-4, k
-    for k in b[2]:
-        assert torch.allclose(a[2][k], b[2][k], rtol=2e-2, atol=2e-3), k
+def test_model_with_fused_glue_bf16_autocast_is_as_accurate_as_aten():
+    """Two bf16 pipelines differ from each other by rounding noise, so both are measured against the float32 run: the
+    fused glue must not be less accurate than the framework kernels it replaces."""
+    ref = _run_model(False, False, 0.25)
+    fused = _run_model(True, True, 0.25)
+    aten = _run_model(False, True, 0.25)
+    worst = 0.0
+    for i in range(len(ref[0])):
+        e_f = (fused[0][i][0] - ref[0][i][0]).abs().max().item()
+        e_a = (aten[0][i][0] - ref[0][i][0]).abs().max().item()
+        assert e_f <= 2.0 * e_a + 1e-3, (i, e_f, e_a)
+    for k in ref[1]:
+        e_f = (fused[1][k] - ref[1][k]).abs().max().item()
+        e_a = (aten[1][k] - ref[1][k]).abs().max().item()
+        assert e_f <= 2.0 * e_a + 1e-4, (k, e_f, e_a)
+        worst = max(worst, e_f / (ref[1][k].abs().max().item() + 1e-6))
+    for k in ref[2]:
+        e_f = (fused[2][k] - ref[2][k]).abs().max().item()
+        e_a = (aten[2][k] - ref[2][k]).abs().max().item()
+        assert e_f <= 2.0 * e_a + 1e-3, (k, e_f, e_a)
