@@ -11,7 +11,8 @@ import shogidrl_amd.models as models
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-for fused in (False, True):
+only = sys.argv[3] if len(sys.argv) > 3 else ""        # "fused" / "aten": run one variant (profiling)
+for fused in ((True,) if only == "fused" else (False,) if only == "aten" else (False, True)):
     models.FUSED_TOWER_GLUE = fused
     torch.manual_seed(0)
     m = models.ResTowerActorCritic().to("cuda").to(memory_format=torch.channels_last)
