@@ -188,6 +188,9 @@ int ksh_ppo_loss_fwd_bwd(const void *logits /*dev [B,A]*/, int logits_dtype, con
  *                   y = [relu](w * (x - mean) / sqrt(var + eps) + b [+ residual]); batch statistics with the
  *                   biased variance; running_mean / running_var (may be NULL) blended with `momentum`, the
  *                   running variance from the unbiased estimate; save_mean / save_invstd [C] for the backward.
+ *                   pre_bias [C] (optional): bias of the convolution that produced x, folded in instead of being
+ *                   added to x first -- BN(x + pb) == BN(x) with the batch mean moved by pb, so it only enters
+ *                   the running mean (its gradient is exactly zero).
  * ksh_bn_fwd_eval   y = [relu]((x - coef[1][c]) * coef[0][c] + coef[2][c] [+ residual]) with caller-computed
  *                   coefficients (eval mode: coef = {w / sqrt(running_var + eps), running_mean, b}).
  * ksh_bn_bwd        gradients of ksh_bn_fwd_train: dx, optional dresidual (= dy masked by the ReLU; pass NULL
@@ -199,7 +202,7 @@ int ksh_ppo_loss_fwd_bwd(const void *logits /*dev [B,A]*/, int logits_dtype, con
  * ---------------------------------------------------------------------------------------------- */
 uint64_t ksh_tower_workspace_bytes(int C);
 int ksh_bn_fwd_train(const void *x, const void *residual /*or NULL*/, void *y, int dtype, int64_t M, int C,
-                     const float *weight, const float *bias, float *running_mean, float *running_var, float momentum,
+                     const float *pre_bias /*or NULL*/, const float *weight, const float *bias, float *running_mean, float *running_var, float momentum,
                      float eps, int relu, float *save_mean, float *save_invstd, void *workspace, void *stream);
 int ksh_bn_fwd_eval(const void *x, const void *residual /*or NULL*/, void *y, int dtype, int64_t M, int C,
                     const float *coef /*dev [3][C]*/, int relu, void *stream);

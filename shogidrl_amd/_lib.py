@@ -72,7 +72,7 @@ def lib():
     i64 = C.c_int64
     L.ksh_tower_workspace_bytes.restype = u64
     L.ksh_tower_workspace_bytes.argtypes = [i32]
-    L.ksh_bn_fwd_train.argtypes = [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp]
+    L.ksh_bn_fwd_train.argtypes = [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp]
     L.ksh_bn_fwd_eval.argtypes = [vp, vp, vp, i32, i64, i32, vp, i32, vp]
     L.ksh_bn_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, vp, vp, vp, i32, vp, vp, vp, vp]
     L.ksh_se_pool.argtypes = [vp, i32, i32, i32, i32, vp, vp]

@@ -368,8 +368,8 @@ static void launch_bn_apply(const void *x, const void *res, void *y, const KshRo
 }
 }  // extern "C++"
 
-int ksh_bn_fwd_train(const void *x, const void *residual, void *y, int dtype, int64_t M, int C, const float *weight,
-                     const float *bias, float *running_mean, float *running_var, float momentum, float eps, int relu,
+int ksh_bn_fwd_train(const void *x, const void *residual, void *y, int dtype, int64_t M, int C, const float *pre_bias,
+                     const float *weight, const float *bias, float *running_mean, float *running_var, float momentum, float eps, int relu,
                      float *save_mean, float *save_invstd, void *workspace, void *stream) {
     if (!tower_shape_ok("ksh_bn_fwd_train", dtype, M, C)) return KSH_E_ARG;
     if (!x || !y || !save_mean || !save_invstd || !workspace) return fail_arg("ksh_bn_fwd_train: null pointer");
@@ -377,10 +377,10 @@ int ksh_bn_fwd_train(const void *x, const void *residual, void *y, int dtype, in
     hipStream_t st = (hipStream_t)stream;
     float *partial = (float *)workspace, *coef = partial + (size_t)KSH_TW_MAXG * 2 * C;
     const KshRowSplit sp = ksh_row_split(M, C, KSH_TW_MAXG);
-    if (dtype == 0) hipLaunchKernelGGL((ksh_bn_stats_kernel<float>), dim3(sp.G), dim3(KSH_TW_THREADS), 0, st, (const float *)x, sp, (const float *)running_mean, partial);
-    else hipLaunchKernelGGL((ksh_bn_stats_kernel<ksh_bf16>), dim3(sp.G), dim3(KSH_TW_THREADS), 0, st, (const ksh_bf16 *)x, sp, (const float *)running_mean, partial);
-    hipLaunchKernelGGL(ksh_bn_finalize_kernel, dim3((C + 31) / 32), dim3(KSH_TW_THREADS), 0, st, (const float *)partial, sp,
-                       (const float *)running_mean, weight, bias, running_mean, running_var, momentum, eps, save_mean,
+    if (dtype == 0) hipLaunchKernelGGL((ksh_bn_stats_kernel<float>), dim3(sp.G), dim3(KSH_TW_THREADS), 0, st, (const float *)x, sp, (const float *)running_mean, pre_bias, partial);
+    else hipLaunchKernelGGL((ksh_bn_stats_kernel<ksh_bf16>), dim3(sp.G), dim3(KSH_TW_THREADS), 0, st, (const ksh_bf16 *)x, sp, (const float *)running_mean, pre_bias, partial);
+    hipLaunchKernelGGL(ksh_bn_finalize_kernel, dim3((C + KSH_TW_FIN_CH - 1) / KSH_TW_FIN_CH), dim3(KSH_TW_THREADS), 0, st,
+                       (const float *)partial, sp, (const float *)running_mean, pre_bias, weight, bias, running_mean, running_var, momentum, eps, save_mean,
                        save_invstd, coef);
     const KshRowSplit sa = ksh_row_split(M, C, 4 * KSH_TW_MAXG);
     if (dtype == 0) launch_bn_apply<float>(x, residual, y, sa, coef, relu, st);
@@ -411,7 +411,7 @@ static void launch_bn_bwd(const void *dy, const void *x, const void *y, void *dx
     const dim3 b(KSH_TW_THREADS);
     if (relu) hipLaunchKernelGGL((ksh_bn_bwd_reduce_kernel<T, 1>), dim3(sp.G), b, 0, st, gp, xp, yp, sp, mean, partial);
     else hipLaunchKernelGGL((ksh_bn_bwd_reduce_kernel<T, 0>), dim3(sp.G), b, 0, st, gp, xp, yp, sp, mean, partial);
-    hipLaunchKernelGGL(ksh_bn_bwd_finalize_kernel, dim3((sp.C + 31) / 32), b, 0, st, (const float *)partial, sp, weight, invstd,
+    hipLaunchKernelGGL(ksh_bn_bwd_finalize_kernel, dim3((sp.C + KSH_TW_FIN_CH - 1) / KSH_TW_FIN_CH), b, 0, st, (const float *)partial, sp, weight, invstd,
                        dw, db, coef);
     const dim3 g(sa.G);
     if (relu && dres) hipLaunchKernelGGL((ksh_bn_bwd_apply_kernel<T, 1, 1>), g, b, 0, st, gp, xp, yp, dxp, drp, sa, mean, (const float *)coef);

@@ -104,6 +104,7 @@ __device__ __forceinline__ void ksh_tw_reduce16(float *red, float a[8], float b[
 template <typename T>
 __global__ void __launch_bounds__(KSH_TW_THREADS) ksh_bn_stats_kernel(const T *__restrict__ x, KshRowSplit sp,
                                                                       const float *__restrict__ shift /*[C] or null*/,
+                                                                      const float *__restrict__ pre_bias /*[C] or null*/,
                                                                       float *__restrict__ partial /*[G][2][C]*/) {
     __shared__ float red[KSH_TW_THREADS * 16];
     const int cg = sp.C >> 3, tcg = (int)threadIdx.x % cg, tr = (int)threadIdx.x / cg, rpp = KSH_TW_THREADS / cg;
@@ -115,7 +116,7 @@ __global__ void __launch_bounds__(KSH_TW_THREADS) ksh_bn_stats_kernel(const T *_
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         s[k] = q[k] = 0.0f;
-        kk[k] = shift != nullptr ? shift[tcg * 8 + k] : 0.0f;
+        kk[k] = shift != nullptr ? shift[tcg * 8 + k] - (pre_bias != nullptr ? pre_bias[tcg * 8 + k] : 0.0f) : 0.0f;
     }
 #pragma unroll 4
     for (long long r = r0 + tr; r < r1; r += rpp) {
@@ -139,36 +140,56 @@ __global__ void __launch_bounds__(KSH_TW_THREADS) ksh_bn_stats_kernel(const T *_
     }
 }
 
-// Per-channel sums of the G partial rows in double: a 256-thread block covers 32 channels x 8 partial-row lanes.
+// Per-channel sums of the G partial rows in double: a 256-thread block covers 16 channels x 16 partial-row lanes
+// (launch with ceil(C / 16) blocks); the loads of a lane are independent, so they are issued eight at a time.
 // Returns true in the threads (lane 0) that hold the totals.
+#define KSH_TW_FIN_CH 16
 __device__ __forceinline__ bool ksh_tw_sum_partials(const float *__restrict__ partial, const KshRowSplit &sp, int &c,
                                                     double &s, double &q) {
     __shared__ double acc[2][KSH_TW_THREADS];
-    const int cl = (int)threadIdx.x & 31, j = (int)threadIdx.x >> 5;
-    c = (int)blockIdx.x * 32 + cl;
+    constexpr int LANES = KSH_TW_THREADS / KSH_TW_FIN_CH;
+    const int cl = (int)threadIdx.x % KSH_TW_FIN_CH, j = (int)threadIdx.x / KSH_TW_FIN_CH;
+    c = (int)blockIdx.x * KSH_TW_FIN_CH + cl;
     s = q = 0.0;
     const int geff = (int)((sp.M + sp.R - 1) / sp.R);
-    if (c < sp.C)
-        for (int g = j; g < geff; g += 8) {
+    if (c < sp.C) {
+        int g = j;
+        for (; g + 7 * LANES < geff; g += 8 * LANES) {
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                a[u] = partial[(size_t)(g + u * LANES) * 2 * sp.C + c];
+                b[u] = partial[(size_t)(g + u * LANES) * 2 * sp.C + sp.C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                s += (double)a[u];
+                q += (double)b[u];
+            }
+        }
+        for (; g < geff; g += LANES) {
             s += (double)partial[(size_t)g * 2 * sp.C + c];
             q += (double)partial[(size_t)g * 2 * sp.C + sp.C + c];
         }
+    }
     acc[0][threadIdx.x] = s;
     acc[1][threadIdx.x] = q;
     __syncthreads();
     if (j != 0 || c >= sp.C) return false;
-    for (int i = 1; i < 8; i++) {
-        s += acc[0][i * 32 + cl];
-        q += acc[1][i * 32 + cl];
+    for (int i = 1; i < LANES; i++) {
+        s += acc[0][i * KSH_TW_FIN_CH + cl];
+        q += acc[1][i * KSH_TW_FIN_CH + cl];
     }
     return true;
 }
 
-// launch with ceil(C / 32) blocks of 256 threads.  coef: [0] scale = w * invstd, [1] mean, [2] bias;
-// running_* may be null; `shift` is the K the stats kernel subtracted (null = 0)
+// launch with ceil(C / 16) blocks of 256 threads.  coef: [0] scale = w * invstd, [1] mean, [2] bias;
+// running_* may be null; `shift` / `pre_bias`: the stats kernel subtracted K = shift - pre_bias (null = 0).
+// pre_bias is the bias of the convolution that produced x, folded in here instead of being added to x: BN(x + pb)
+// equals BN(x) with the batch mean moved by pb, so only the running mean sees it.
 extern "C" __global__ void __launch_bounds__(KSH_TW_THREADS)
 ksh_bn_finalize_kernel(const float *__restrict__ partial, KshRowSplit sp, const float *__restrict__ shift,
-                       const float *__restrict__ w, const float *__restrict__ b, float *running_mean, float *running_var,
+                       const float *__restrict__ pre_bias, const float *__restrict__ w, const float *__restrict__ b, float *running_mean, float *running_var,
                        float momentum, float eps, float *__restrict__ save_mean, float *__restrict__ save_invstd,
                        float *__restrict__ coef /*[3][C]*/) {
     int c;
@@ -178,13 +199,14 @@ ksh_bn_finalize_kernel(const float *__restrict__ partial, KshRowSplit sp, const 
     const double dm = s / n;                          // mean of (x - K)
     double m2 = q - s * dm;                           // sum of squared deviations from the mean
     if (m2 < 0.0) m2 = 0.0;
-    const double mean = dm + (shift != nullptr ? (double)shift[c] : 0.0);
+    const float pb = pre_bias != nullptr ? pre_bias[c] : 0.0f;
+    const double mean = dm + (shift != nullptr ? (double)(shift[c] - pb) : 0.0);     // batch mean of x itself
     const double var = m2 / n;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float fmean = (float)mean;
     save_mean[c] = fmean;
     save_invstd[c] = invstd;
-    if (running_mean != nullptr) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * fmean;
+    if (running_mean != nullptr) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (fmean + pb);
     if (running_var != nullptr) {
         const float unbiased = (float)(n > 1.0 ? m2 / (n - 1.0) : var);
         running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
@@ -266,7 +288,7 @@ __global__ void __launch_bounds__(KSH_TW_THREADS) ksh_bn_bwd_reduce_kernel(const
     }
 }
 
-// launch with ceil(C / 32) blocks of 256 threads.  coef: [0] a = w * invstd, [1] k1 = sum(dz) / M,
+// launch with ceil(C / 16) blocks of 256 threads.  coef: [0] a = w * invstd, [1] k1 = sum(dz) / M,
 // [2] k2 = invstd^2 * sum(dz * (x - mean)) / M;  dw / db may be null
 extern "C" __global__ void __launch_bounds__(KSH_TW_THREADS)
 ksh_bn_bwd_finalize_kernel(const float *__restrict__ partial, KshRowSplit sp, const float *__restrict__ w,

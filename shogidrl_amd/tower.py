@@ -67,7 +67,7 @@ def _ptr(t):
 
 class _BNActTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, residual, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, residual, pre_bias, momentum, eps, relu):
         N, C, H, W = x.shape
         M = N * H * W
         y = _like(x)
@@ -75,13 +75,15 @@ class _BNActTrain(torch.autograd.Function):
         invstd = torch.empty(C, dtype=torch.float32, device=x.device)
         w = None if weight is None else weight.detach().float().contiguous()
         b = None if bias is None else bias.detach().float().contiguous()
-        check(lib().ksh_bn_fwd_train(x.data_ptr(), _ptr(residual), y.data_ptr(), _code(x), M, C, _ptr(w), _ptr(b),
+        pb = None if pre_bias is None else pre_bias.detach().float().contiguous()
+        check(lib().ksh_bn_fwd_train(x.data_ptr(), _ptr(residual), y.data_ptr(), _code(x), M, C, _ptr(pb), _ptr(w), _ptr(b),
                                      _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), int(relu),
                                      mean.data_ptr(), invstd.data_ptr(), _workspace(x.device, C).data_ptr(), _stream()),
               "ksh_bn_fwd_train")
         ctx.save_for_backward(x, y if relu else None, w, mean, invstd)
         ctx.relu, ctx.has_res = bool(relu), residual is not None
         ctx.has_w, ctx.has_b = weight is not None, bias is not None
+        ctx.pre_bias = None if pre_bias is None else (pre_bias.shape, pre_bias.dtype)
         return y
 
     @staticmethod
@@ -98,12 +100,16 @@ class _BNActTrain(torch.autograd.Function):
                                _workspace(x.device, C).data_ptr(), _stream()), "ksh_bn_bwd")
         if ctx.has_res and not ctx.relu:
             dres = dy                                        # no ReLU in between: the residual's gradient is dy itself
-        return (dx, dw if ctx.has_w else None, db if ctx.has_b else None, None, None, dres if ctx.has_res else None,
+        # a bias added before the normalisation cannot change the output: its gradient is exactly zero
+        dpb = None if ctx.pre_bias is None else torch.zeros(ctx.pre_bias[0], dtype=ctx.pre_bias[1], device=x.device)
+        return (dx, dw if ctx.has_w else None, db if ctx.has_b else None, None, None, dres if ctx.has_res else None, dpb,
                 None, None, None)
 
 
-def bn_act(x, bn, residual=None, relu=False):
-    """[relu](bn(x) [+ residual]) for an nn.BatchNorm2d `bn` through the fused kernels.  Returns None when this call
+def bn_act(x, bn, residual=None, relu=False, pre_bias=None):
+    """[relu](bn(x [+ pre_bias]) [+ residual]) for an nn.BatchNorm2d `bn` through the fused kernels; `pre_bias` [C] is
+    the bias of the convolution that produced `x`, folded into the statistics instead of being added (and reduced in
+    the backward) by separate kernels.  Returns None when this call
     is not covered (CPU tensors, channel counts such as the 2-plane heads, eval mode under autograd, cumulative-average
     momentum) -- the caller then runs the same computation through ATen (models._BN)."""
     if not supported(x) or bn.momentum is None:
@@ -116,15 +122,17 @@ def bn_act(x, bn, residual=None, relu=False):
             bn.num_batches_tracked.add_(1)
         rm = bn.running_mean if bn.track_running_stats else None
         rv = bn.running_var if bn.track_running_stats else None
-        return _BNActTrain.apply(x, bn.weight, bn.bias, rm, rv, residual, bn.momentum, bn.eps, relu)
-    if torch.is_grad_enabled() and (x.requires_grad or (bn.weight is not None and bn.weight.requires_grad)):
+        return _BNActTrain.apply(x, bn.weight, bn.bias, rm, rv, residual, pre_bias, bn.momentum, bn.eps, relu)
+    if torch.is_grad_enabled() and (x.requires_grad or (bn.weight is not None and bn.weight.requires_grad)
+                                    or (pre_bias is not None and pre_bias.requires_grad)):
         return None
     with torch.no_grad():
         scale = torch.rsqrt(bn.running_var.float() + bn.eps)
         if bn.weight is not None:
             scale = scale * bn.weight.float()
         bias = bn.bias.float() if bn.bias is not None else torch.zeros_like(scale)
-        coef = torch.stack([scale, bn.running_mean.float(), bias]).contiguous()
+        mean = bn.running_mean.float() if pre_bias is None else bn.running_mean.float() - pre_bias.float()
+        coef = torch.stack([scale, mean, bias]).contiguous()
         N, C, H, W = x.shape
         y = _like(x)
         check(lib().ksh_bn_fwd_eval(x.data_ptr(), _ptr(residual), y.data_ptr(), _code(x), N * H * W, C, coef.data_ptr(),

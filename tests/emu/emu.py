@@ -198,7 +198,7 @@ class EmuTower:
         vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
         self.L.emu_tower_workspace_floats.restype = i64
         self.L.emu_tower_workspace_floats.argtypes = [i32]
-        self.L.emu_bn_fwd_train.argtypes = [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp]
+        self.L.emu_bn_fwd_train.argtypes = [vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp]
         self.L.emu_bn_fwd_eval.argtypes = [vp, vp, vp, i32, i64, i32, vp, i32]
         self.L.emu_bn_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, vp, vp, vp, i32, vp, vp, vp]
         self.L.emu_se_pool.argtypes = [vp, i32, i32, i32, i32, vp]
@@ -224,13 +224,13 @@ class EmuTower:
     def _ws(self, Cn):
         return np.zeros(self.L.emu_tower_workspace_floats(Cn), np.float32)
 
-    def bn_fwd_train(self, x, res, bf16, w, b, rm, rv, momentum, eps, relu):
+    def bn_fwd_train(self, x, res, bf16, w, b, rm, rv, momentum, eps, relu, pre_bias=None):
         M, Cn = x.shape
         p = lambda t: None if t is None else t.ctypes.data
         xi, ri, y = self._in(x, bf16), self._in(res, bf16), self._out(x.shape, bf16)
         mean, invstd = np.zeros(Cn, np.float32), np.zeros(Cn, np.float32)
         ws = self._ws(Cn)
-        self.L.emu_bn_fwd_train(p(xi), p(ri), p(y), int(bf16), M, Cn, p(w), p(b), p(rm), p(rv), momentum, eps, int(relu),
+        self.L.emu_bn_fwd_train(p(xi), p(ri), p(y), int(bf16), M, Cn, p(pre_bias), p(w), p(b), p(rm), p(rv), momentum, eps, int(relu),
                                 p(mean), p(invstd), p(ws))
         return self._f(y, bf16), rm, rv, mean, invstd
 

@@ -7,12 +7,12 @@
 namespace {
 struct A {
     const void *x, *res, *dy, *y; void *out, *out2; int dtype, relu; KshRowSplit sp; const float *w, *b, *mean, *invstd, *shift;
-    float *rm, *rv, *save_mean, *save_invstd, *partial, *coef, *dw, *db; float momentum, eps;
+    float *rm, *rv, *save_mean, *save_invstd, *partial, *coef, *dw, *db; const float *pre_bias; float momentum, eps;
     int HW, C; const float *s, *dp; float *p;
 } a;
-template <typename T> void stats_t() { ksh_bn_stats_kernel<T>((const T *)a.x, a.sp, a.shift, a.partial); }
+template <typename T> void stats_t() { ksh_bn_stats_kernel<T>((const T *)a.x, a.sp, a.shift, a.pre_bias, a.partial); }
 void stats_entry(void *) { a.dtype ? stats_t<ksh_bf16>() : stats_t<float>(); }
-void fin_entry(void *) { ksh_bn_finalize_kernel(a.partial, a.sp, a.shift, a.w, a.b, a.rm, a.rv, a.momentum, a.eps, a.save_mean, a.save_invstd, a.coef); }
+void fin_entry(void *) { ksh_bn_finalize_kernel(a.partial, a.sp, a.shift, a.pre_bias, a.w, a.b, a.rm, a.rv, a.momentum, a.eps, a.save_mean, a.save_invstd, a.coef); }
 template <typename T> void apply_t() {
     const T *x = (const T *)a.x, *r = (const T *)a.res; T *y = (T *)a.out;
     if (a.relu && r) ksh_bn_apply_kernel<T, 1, 1>(x, r, y, a.sp, a.coef);
@@ -48,16 +48,16 @@ void run(void (*e)(void *), int blocks) { for (int b = 0; b < blocks; b++) emu::
 
 extern "C" {
 long long emu_tower_workspace_floats(int C) { return ((long long)KSH_TW_MAXG * 2 + 3) * C; }
-void emu_bn_fwd_train(const void *x, const void *res, void *y, int dtype, long long M, int C, const float *w, const float *b,
+void emu_bn_fwd_train(const void *x, const void *res, void *y, int dtype, long long M, int C, const float *pre_bias, const float *w, const float *b,
                       float *rm, float *rv, float momentum, float eps, int relu, float *save_mean, float *save_invstd,
                       float *ws) {
     a = A{};
-    a.x = x; a.res = res; a.out = y; a.dtype = dtype; a.relu = relu; a.w = w; a.b = b; a.rm = rm; a.rv = rv; a.shift = rm;
+    a.x = x; a.res = res; a.out = y; a.dtype = dtype; a.relu = relu; a.w = w; a.b = b; a.rm = rm; a.rv = rv; a.shift = rm; a.pre_bias = pre_bias;
     a.momentum = momentum; a.eps = eps; a.save_mean = save_mean; a.save_invstd = save_invstd;
     a.partial = ws; a.coef = ws + (size_t)KSH_TW_MAXG * 2 * C;
     a.sp = ksh_row_split(M, C, KSH_TW_MAXG);
     run(stats_entry, a.sp.G);
-    run(fin_entry, (C + 31) / 32);
+    run(fin_entry, (C + KSH_TW_FIN_CH - 1) / KSH_TW_FIN_CH);
     a.sp = ksh_row_split(M, C, 4 * KSH_TW_MAXG);
     run(apply_entry, a.sp.G);
 }
@@ -74,7 +74,7 @@ void emu_bn_bwd(const void *dy, const void *x, const void *y, void *dx, void *dr
     a.invstd = invstd; a.dw = dw; a.db = db; a.partial = ws; a.coef = ws + (size_t)KSH_TW_MAXG * 2 * C;
     a.sp = ksh_row_split(M, C, KSH_TW_MAXG);
     run(bred_entry, a.sp.G);
-    run(bfin_entry, (C + 31) / 32);
+    run(bfin_entry, (C + KSH_TW_FIN_CH - 1) / KSH_TW_FIN_CH);
     a.sp = ksh_row_split(M, C, 4 * KSH_TW_MAXG);
     run(bapp_entry, a.sp.G);
 }

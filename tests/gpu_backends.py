@@ -120,14 +120,14 @@ class GpuTower:
     def _ws(self, C):
         return torch.empty(self.L.ksh_tower_workspace_bytes(C) // 4, dtype=torch.float32, device=DEV)
 
-    def bn_fwd_train(self, x, res, bf16, w, b, rm, rv, momentum, eps, relu):
+    def bn_fwd_train(self, x, res, bf16, w, b, rm, rv, momentum, eps, relu, pre_bias=None):
         M, C = x.shape
         p = lambda t: None if t is None else t.data_ptr()
         xt, rt = self._t(x, bf16), self._t(res, bf16)
         y = torch.full_like(xt, float("nan"))
-        wt, bt, rmt, rvt = self._t(w), self._t(b), self._t(rm), self._t(rv)
+        wt, bt, rmt, rvt, pbt = self._t(w), self._t(b), self._t(rm), self._t(rv), self._t(pre_bias)
         mean, invstd, ws = torch.empty(C, device=DEV), torch.empty(C, device=DEV), self._ws(C)
-        self.check(self.L.ksh_bn_fwd_train(p(xt), p(rt), p(y), int(bf16), M, C, p(wt), p(bt), p(rmt), p(rvt), momentum, eps,
+        self.check(self.L.ksh_bn_fwd_train(p(xt), p(rt), p(y), int(bf16), M, C, p(pbt), p(wt), p(bt), p(rmt), p(rvt), momentum, eps,
                                            int(relu), p(mean), p(invstd), p(ws), self.st()), "ksh_bn_fwd_train")
         return self._np(y), self._np(rmt), self._np(rvt), self._np(mean), self._np(invstd)
 

@@ -26,6 +26,11 @@ def test_gpu_bn_statistics_with_large_mean(be):
     towercheck.check_bn(be, (4, 32, 9, 9), False, True, False, seed=3, mean_offset=300.0)
 
 
+def test_gpu_bn_folded_conv_bias(be):
+    towercheck.check_bn(be, (4, 64, 9, 9), False, True, False, seed=5, pre_bias=True)
+    towercheck.check_bn(be, (130, 256, 9, 9), True, False, True, seed=6, pre_bias=True)
+
+
 def test_gpu_bn_eval(be):
     towercheck.check_bn_eval(be, (3, 64, 9, 9), False, True, True, seed=1)
     towercheck.check_bn_eval(be, (200, 256, 9, 9), True, False, False, seed=2)

@@ -20,7 +20,7 @@ def _nchw(m, shape):
     return np.ascontiguousarray(m.reshape(N, H, W, C).transpose(0, 3, 1, 2))
 
 
-def check_bn(be, shape, bf16, relu, residual, seed, mean_offset=0.0):
+def check_bn(be, shape, bf16, relu, residual, seed, mean_offset=0.0, pre_bias=False):
     """training-mode forward (outputs, saved statistics, running-stat update) and backward (dx, dresidual, dw, db)"""
     N, C, H, W = shape
     rng = np.random.default_rng(seed)
@@ -31,6 +31,7 @@ def check_bn(be, shape, bf16, relu, residual, seed, mean_offset=0.0):
     b = rng.uniform(-0.5, 0.5, C).astype(np.float32)
     rm0 = rng.uniform(-0.2, 0.2, C).astype(np.float32) + np.float32(mean_offset)
     rv0 = rng.uniform(0.5, 1.5, C).astype(np.float32)
+    pb = rng.uniform(-1.0, 1.0, C).astype(np.float32) if pre_bias else None
     if bf16:
         x, dy = _bf16_round(x), _bf16_round(dy)
         res = _bf16_round(res) if residual else None
@@ -39,7 +40,8 @@ def check_bn(be, shape, bf16, relu, residual, seed, mean_offset=0.0):
     tr = torch.tensor(res, requires_grad=True) if residual else None
     tw, tb = torch.tensor(w, requires_grad=True), torch.tensor(b, requires_grad=True)
     trm, trv = torch.tensor(rm0.copy()), torch.tensor(rv0.copy())
-    ty = F.batch_norm(tx, trm, trv, tw, tb, True, 0.1, 1e-5)
+    # a folded convolution bias: the reference adds it to x before the normalisation
+    ty = F.batch_norm(tx if pb is None else tx + torch.tensor(pb)[None, :, None, None], trm, trv, tw, tb, True, 0.1, 1e-5)
     if residual:
         ty = ty + tr
     if relu:
@@ -47,13 +49,15 @@ def check_bn(be, shape, bf16, relu, residual, seed, mean_offset=0.0):
     y_ref = ty.detach().numpy()
     ty.backward(torch.tensor(dy))
     # ---- kernels
-    out = be.bn_fwd_train(_nhwc(x), None if res is None else _nhwc(res), bf16, w, b, rm0.copy(), rv0.copy(), 0.1, 1e-5, relu)
+    out = be.bn_fwd_train(_nhwc(x), None if res is None else _nhwc(res), bf16, w, b, rm0.copy(), rv0.copy(), 0.1, 1e-5, relu,
+                          **({"pre_bias": pb} if pre_bias else {}))
     y, rm, rv, mean, invstd = out
     tol = dict(rtol=1e-2, atol=1e-2) if bf16 else dict(rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(_nchw(y, shape), y_ref, **tol)
     xm = x.transpose(1, 0, 2, 3).reshape(C, -1).astype(np.float64)
     np.testing.assert_allclose(mean, xm.mean(1), rtol=1e-5, atol=1e-5 * (1 + abs(mean_offset)))
     np.testing.assert_allclose(invstd, 1.0 / np.sqrt(xm.var(1) + 1e-5), rtol=2e-5)
+    # save_mean is the batch mean of x itself; the running mean includes the folded bias
     np.testing.assert_allclose(rm, trm.numpy(), rtol=1e-5, atol=1e-6 * (1 + abs(mean_offset)))
     np.testing.assert_allclose(rv, trv.numpy(), rtol=2e-5, atol=1e-6)
     dx, dres, dw, db = be.bn_bwd(_nhwc(dy), _nhwc(x), y if relu else None, bf16, w, mean, invstd, relu, residual)
