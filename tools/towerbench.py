@@ -9,6 +9,8 @@ import torch
 
 import shogidrl_amd.models as models
 
+torch.backends.cudnn.benchmark = os.environ.get("KSH_CUDNN_BENCHMARK", "0") == "1"     # MIOpen exhaustive find
+
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 only = sys.argv[3] if len(sys.argv) > 3 else ""        # "fused" / "aten": run one variant (profiling)
