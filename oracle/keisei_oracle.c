@@ -584,6 +584,39 @@ void ko_vec_step(KoGame **games, int n, const int64_t *actions, float *obs, uint
     }
 }
 
+/* Uniform-random legal self-play of n games for `steps` batched steps, entirely in C (no interpreter between steps):
+ * the CPU-baseline loop of bench.py when several host threads run at once.  Each step is ko_vec_step's work (move,
+ * termination, auto-reset, 46-plane observation, 13 527-byte mask) with the action drawn from the previous mask by a
+ * xorshift64* stream.  obs / mask: caller-provided scratch of n rows.  Returns the number of env steps made. */
+long long ko_selfplay_random(KoGame **games, int n, int steps, uint64_t seed, float *obs, uint8_t *mask) {
+    uint64_t x = seed ? seed : 0x9E3779B97F4A7C15ull;
+    long long made = 0;
+    int32_t *nl = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+    if (!nl) return 0;
+    for (int i = 0; i < n; i++) nl[i] = ko_legal_mask(games[i], mask + (size_t)i * KO_NUM_ACTIONS);
+    for (int s = 0; s < steps; s++) {
+        for (int i = 0; i < n; i++) {
+            KoGame *g = games[i];
+            uint8_t *m = mask + (size_t)i * KO_NUM_ACTIONS;
+            if (nl[i] <= 0) { ko_reset(g); nl[i] = ko_legal_mask(g, m); }
+            x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+            int k = (int)(((x * 0x2545F4914F6CDD1Dull) >> 33) % (uint64_t)nl[i]);
+            int a = 0;
+            for (; a < KO_NUM_ACTIONS; a++)
+                if (m[a] && k-- == 0) break;
+            float rw = 0.0f;
+            int dn = 0;
+            (void)ko_make_move(g, a, &rw, &dn);
+            if (dn) ko_reset(g);
+            ko_observation(g, obs + (size_t)i * KO_OBS_SIZE);
+            nl[i] = ko_legal_mask(g, m);
+            made++;
+        }
+    }
+    free(nl);
+    return made;
+}
+
 /* ------------------------------------------------------------------ GAE */
 /* ref: core/experience_buffer.py:99-145.  torch evaluates, on 0-d float32 tensors:
  *   delta = r[t] + gamma * next_v * mask[t] - v[t]          (left to right, gamma is a Python float

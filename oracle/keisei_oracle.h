@@ -65,6 +65,7 @@ int     ko_decode_action(int action, int *from_sq, int *to_sq, int *aux);
 
 /* Batched helper used as the CPU baseline: n independent games, one env step each with auto-reset
  * (step_manager.py:98-348, 437-468).  Outputs have the same layout as ksh_env_step. */
+long long ko_selfplay_random(KoGame **games, int n, int steps, uint64_t seed, float *obs, uint8_t *mask);
 void    ko_vec_step(KoGame **games, int n, const int64_t *actions, float *obs, uint8_t *mask,
                     int32_t *n_legal, float *reward, uint8_t *done, uint8_t *reason, int8_t *winner,
                     int auto_reset);

@@ -45,6 +45,8 @@ def lib():
         L.ko_encode_action.argtypes = [C.c_int, C.c_int, C.c_int]
         L.ko_decode_action.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ko_vec_step.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int]
+        L.ko_selfplay_random.restype = C.c_longlong
+        L.ko_selfplay_random.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]
         L.ko_gae.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
                              C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
@@ -155,6 +157,14 @@ class VecGames:
                             nl.ctypes.data, rew.ctypes.data, done.ctypes.data, reason.ctypes.data,
                             winner.ctypes.data, int(auto_reset))
         return obs, mask, nl, rew, done, reason, winner
+
+
+def selfplay_random(vec, steps, seed):
+    """`steps` batched uniform-random self-play steps of a VecGames, all inside the C library (GIL released)."""
+    obs = np.zeros((vec.n, OBS_SIZE), np.float32)
+    mask = np.zeros((vec.n, NUM_ACTIONS), np.uint8)
+    return int(vec._L.ko_selfplay_random(C.cast(vec._ptrs, C.c_void_p), vec.n, int(steps), int(seed), obs.ctypes.data,
+                                         mask.ctypes.data))
 
 
 def gae(rewards, values, dones, last_values, gamma, lam):

@@ -132,3 +132,31 @@ def test_traces_fixture_full_games():
         assert g.game_over
         seen_reasons.add(g.reason)
     assert {1, 3} <= seen_reasons
+
+
+def test_c_selfplay_loop_is_the_checked_step_path():
+    """bench.py's CPU-baseline loop (ko_selfplay_random) makes the same moves as the Python-driven loop over the pinned
+    entry points when the same xorshift64* stream picks the actions."""
+    import numpy as np
+    from oracle import ko
+    vec = ko.VecGames(3, 60)
+    steps, seed = 90, 77
+    assert ko.selfplay_random(vec, steps, seed) == 3 * steps
+    ref = [ko.Game(60) for _ in range(3)]
+    x = seed
+    M = (1 << 64) - 1
+    for _ in range(steps):
+        for g in ref:
+            ids = g.legal_ids()
+            if len(ids) == 0:
+                g.reset()
+                ids = g.legal_ids()
+            x ^= x >> 12
+            x = (x ^ (x << 25)) & M
+            x ^= x >> 27
+            k = ((x * 0x2545F4914F6CDD1D) & M) >> 33
+            _, done = g.make_move(int(np.sort(ids)[k % len(ids)]))
+            if done:
+                g.reset()
+    for a, b in zip(vec.games, ref):
+        assert np.array_equal(a.export_state(), b.export_state())
