@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--compact", action="store_true",
                     help="SURVEY 8f4 formats for the whole-job loop: bit-packed masks + bf16 channels-last observations "
                          "(NOT the reference contract; the default run and the roofline replay keep float32 / byte masks)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the T-step self-play rollout from one captured hipGraph (BASELINE configs[4])")
     ap.add_argument("--roofline-only", action="store_true", help="only time the env kernel (quick check)")
     return ap.parse_args()
 
@@ -190,8 +192,15 @@ def main():
             print("[bench %7.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
     t_start = time.perf_counter()
+    collect = runner.collect
+    if args.graph:
+        runner.collect_graphed()                 # eager (allocations, MIOpen solver choice) ...
+        runner.buffer.clear()
+        runner.collect_graphed()                 # ... capture + first replay; from here on replays only
+        runner.buffer.clear()
+        collect = runner.collect_graphed
     for i in range(args.warmup):
-        runner.collect()
+        collect()
         torch.cuda.synchronize()
         note("warmup %d: rollout done" % i)
         runner.update()
@@ -204,7 +213,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         t_roll.start()
-        runner.collect()
+        collect()
         t_roll.stop()
         t_upd.start()
         metrics = runner.update()
@@ -240,7 +249,8 @@ def main():
                             "(random init), bf16 autocast tower / fp32 heads, rollout T=%d, GAE, PPO %d epochs x "
                             "minibatch %d, Adam" % (args.games, args.depth, args.width, args.rollout, args.epochs, args.minibatch),
                 "games_per_gpu": args.games, "rollout_len": args.rollout, "ppo_epochs": args.epochs,
-                "minibatch_size": args.minibatch, "parallelism": "dp%d (games sharded, flat-gradient all-reduce)" % world,
+                "minibatch_size": args.minibatch, "rollout": "hipGraph replay" if args.graph else "eager launches",
+                "parallelism": "dp%d (games sharded, flat-gradient all-reduce)" % world,
                 "env_dtype": ("u32 bitboards -> bf16 channels-last obs / bit-packed mask (compact, SURVEY 8f4)" if args.compact
                               else "u32 bitboards -> f32 obs / u8 mask"),
             },

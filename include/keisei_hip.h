@@ -145,6 +145,12 @@ int ksh_env_get_state(void *handle, int game, uint8_t *state128 /*host*/, void *
 int ksh_masked_sample(const void *logits /*dev [B,A]*/, int logits_dtype, const uint8_t *mask /*dev [B,A]*/,
                       int B, uint64_t seed, uint64_t step, int deterministic,
                       int64_t *action /*dev [B]*/, float *log_prob /*dev [B]*/, void *stream);
+/* The same sampler for hipGraph-captured rollouts: the Philox step counter is read from device memory at run time
+ * (`step_counter`, one uint64 the caller increments inside the graph), so a replayed graph draws fresh numbers.  Exactly
+ * one of mask (bytes) / mask_bits (packed) is non-NULL.  ksh_masked_sample(..., step = s) == this with *step_counter = s. */
+int ksh_masked_sample_graph(const void *logits /*dev [B,A]*/, int logits_dtype, const uint8_t *mask, const uint32_t *mask_bits,
+                            int B, uint64_t seed, const uint64_t *step_counter /*dev*/, int deterministic,
+                            int64_t *action /*dev [B]*/, float *log_prob /*dev [B]*/, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GAE.  Replaces ExperienceBuffer.compute_advantages_and_returns (core/experience_buffer.py:99-145)

@@ -69,6 +69,7 @@ class VecPPOAgent:
             self.optimizer = torch.optim.Adam(params, **kw)
         self._rng = np.random.default_rng(self.config.seed)       # minibatch shuffling (ppo_agent.py:100, 298)
         self._sample_step = 0
+        self._step_tensor = None        # device-side twin of _sample_step while a captured rollout graph is in use
         self.last_kl_div = 0.0
         self.last_gradient_norm = 0.0
 
@@ -87,6 +88,11 @@ class VecPPOAgent:
         """obs [N,46,9,9], legal_mask bool [N,13527] -> (action int64 [N], log_prob [N], value [N])."""
         self.model.train(is_training)                              # BatchNorm uses batch statistics while acting
         logits, value = self._forward(obs)
+        if self._step_tensor is not None:                          # graph-captured rollout: counter lives on the device
+            action, logp = ops.masked_sample(logits, legal_mask, self.config.seed, self._step_tensor,
+                                             deterministic=not is_training)
+            self._step_tensor.add_(1)
+            return action, logp, value
         action, logp = ops.masked_sample(logits, legal_mask, self.config.seed, self._sample_step,
                                          deterministic=not is_training)
         self._sample_step += 1

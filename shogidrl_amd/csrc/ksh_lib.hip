@@ -221,7 +221,16 @@ int ksh_env_get_state(void *handle, int game, uint8_t *state128, void *stream) {
 
 // ---------------------------------------------------------------------------------- PPO-side kernels
 static int sample_impl(const void *logits, int logits_dtype, const uint8_t *mask, const uint32_t *mask_bits, int B,
-                       uint64_t seed, uint64_t step, int deterministic, int64_t *action, float *log_prob, void *stream);
+                       uint64_t seed, uint64_t step, int deterministic, int64_t *action, float *log_prob, void *stream,
+                       const uint64_t *step_dev = nullptr);
+
+int ksh_masked_sample_graph(const void *logits, int logits_dtype, const uint8_t *mask, const uint32_t *mask_bits, int B,
+                            uint64_t seed, const uint64_t *step_counter, int deterministic, int64_t *action, float *log_prob,
+                            void *stream) {
+    if ((!mask && !mask_bits) || !step_counter) return fail_arg("ksh_masked_sample_graph: bad argument");
+    return sample_impl(logits, logits_dtype, mask_bits ? nullptr : mask, mask_bits, B, seed, 0, deterministic, action,
+                       log_prob, stream, step_counter);
+}
 
 int ksh_masked_sample(const void *logits, int logits_dtype, const uint8_t *mask, int B, uint64_t seed, uint64_t step,
                       int deterministic, int64_t *action, float *log_prob, void *stream) {
@@ -236,16 +245,19 @@ int ksh_masked_sample_packed(const void *logits, int logits_dtype, const uint32_
 }
 
 static int sample_impl(const void *logits, int logits_dtype, const uint8_t *mask, const uint32_t *mask_bits, int B,
-                       uint64_t seed, uint64_t step, int deterministic, int64_t *action, float *log_prob, void *stream) {
+                       uint64_t seed, uint64_t step, int deterministic, int64_t *action, float *log_prob, void *stream,
+                       const uint64_t *step_dev) {
     if (!logits || !action || !log_prob || B <= 0) return fail_arg("ksh_masked_sample: bad argument");
     if (logits_dtype != 0 && logits_dtype != 1) return fail_arg("ksh_masked_sample: logits_dtype must be 0 (f32) or 1 (bf16)");
     const dim3 grid((B + KSH_SAMPLE_WPB - 1) / KSH_SAMPLE_WPB), block(64 * KSH_SAMPLE_WPB);
     if (logits_dtype == 0)
         hipLaunchKernelGGL(ksh_masked_sample_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float *)logits, mask,
-                           mask_bits, B, seed, step, deterministic, reinterpret_cast<long long *>(action), log_prob);
+                           mask_bits, B, seed, step, reinterpret_cast<const unsigned long long *>(step_dev), deterministic,
+                           reinterpret_cast<long long *>(action), log_prob);
     else
         hipLaunchKernelGGL(ksh_masked_sample_kernel<ksh_bf16>, grid, block, 0, (hipStream_t)stream,
-                           (const ksh_bf16 *)logits, mask, mask_bits, B, seed, step, deterministic,
+                           (const ksh_bf16 *)logits, mask, mask_bits, B, seed, step,
+                           reinterpret_cast<const unsigned long long *>(step_dev), deterministic,
                            reinterpret_cast<long long *>(action), log_prob);
     HIP_TRY(hipGetLastError());
     return KSH_OK;

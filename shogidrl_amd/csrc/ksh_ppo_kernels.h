@@ -246,14 +246,16 @@ template <typename T>
 __global__ void __launch_bounds__(64 * KSH_SAMPLE_WPB)
 ksh_masked_sample_kernel(const T *__restrict__ logits, const uint8_t *__restrict__ mask,
                          const uint32_t *__restrict__ mask_bits, int B, unsigned long long seed,
-                         unsigned long long step, int deterministic, long long *__restrict__ action,
-                         float *__restrict__ log_prob) {
+                         unsigned long long step, const unsigned long long *__restrict__ step_dev, int deterministic,
+                         long long *__restrict__ action, float *__restrict__ log_prob) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * KSH_SAMPLE_WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (b >= B) return;  // wave-uniform
     const uint8_t *mrow = mask + (mask_bits != nullptr ? (size_t)0 : (size_t)b * KSH_PA);
     const T *row = logits + (size_t)b * KSH_PA;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    // the Philox counter of this call: an immediate, plus (graph-captured rollouts) a counter that lives on the device
+    if (step_dev != nullptr) step += step_dev[0];
     const uint32_t s0 = (uint32_t)step, s1 = (uint32_t)(step >> 32);
     const bool det = deterministic != 0;
     KshSampleAcc A = {-INFINITY, 0.0f, -INFINITY, 0.0f, -1};

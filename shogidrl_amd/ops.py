@@ -57,12 +57,25 @@ def unpack_mask(bits):
 
 
 def masked_sample(logits, legal_mask, seed, step, deterministic=False):
-    """logits [B,13527] f32|bf16, legal_mask [B,13527] bool -> (action int64 [B], log_prob f32 [B])."""
+    """logits [B,13527] f32|bf16, legal_mask [B,13527] bool (or packed int32 [B,424]) -> (action int64 [B],
+    log_prob f32 [B]).  `step`: the Philox step counter -- a Python int, or a one-element int64 CUDA tensor read by the
+    kernel at run time (hipGraph-captured rollouts: increment the tensor inside the graph)."""
     _need_cuda(logits, legal_mask)
     B = logits.shape[0]
     logits = logits.contiguous()
     action = torch.empty(B, dtype=torch.int64, device=logits.device)
     logp = torch.empty(B, dtype=torch.float32, device=logits.device)
+    if isinstance(step, torch.Tensor):
+        if step.dtype != torch.int64 or step.numel() != 1 or step.device != logits.device:
+            raise TypeError("a device step counter must be a one-element int64 tensor on the logits' device")
+        packed = is_packed(legal_mask)
+        assert logits.shape == (B, NUM_ACTIONS) and legal_mask.shape == (B, MASK_WORDS if packed else NUM_ACTIONS)
+        legal_mask = legal_mask.contiguous() if packed else _mask_u8(legal_mask)
+        check(lib().ksh_masked_sample_graph(logits.data_ptr(), _dtype_code(logits), None if packed else legal_mask.data_ptr(),
+                                            legal_mask.data_ptr() if packed else None, B, int(seed), step.data_ptr(),
+                                            int(bool(deterministic)), action.data_ptr(), logp.data_ptr(), _stream()),
+              "ksh_masked_sample_graph")
+        return action, logp
     if is_packed(legal_mask):
         assert logits.shape == (B, NUM_ACTIONS) and legal_mask.shape == (B, MASK_WORDS)
         legal_mask = legal_mask.contiguous()

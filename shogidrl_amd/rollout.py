@@ -19,7 +19,42 @@ class SelfPlayRunner:
         env.auto_reset = True
         env.reset(out_obs=buffer.obs[0], out_mask=buffer.legal_masks[0])
 
+    def collect_graphed(self):
+        """collect() replayed from one hipGraph (BASELINE configs[4]: "hipGraph-captured rollout step").  Everything in
+        the T-step loop is device work on fixed buffers -- the policy forward, the sampler (its Philox counter is a
+        device tensor the graph increments), the env kernel writing slot t+1, the bookkeeping -- so the whole rollout
+        is captured once and replayed with a single launch; trajectories are identical to collect()'s
+        (tests/test_gpu_agent.py).  The first call runs one eager rollout (allocations, MIOpen solver choice), the
+        second captures, later calls replay."""
+        agent = self.agent
+        if getattr(self, "_graph", None) is not None:
+            self._graph.replay()
+            agent._sample_step += self.buffer.T
+            self.global_timestep += self.buffer.T * self.buffer.N
+            return
+        if not getattr(self, "_graph_warm", False):
+            self._graph_warm = True
+            return self.collect()
+        agent._step_tensor = torch.tensor([agent._sample_step], dtype=torch.int64, device=self.env.device)
+        side = torch.cuda.Stream(device=self.env.device)
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                self._collect_body()
+        torch.cuda.current_stream().wait_stream(side)
+        self._graph = graph
+        graph.replay()                     # capture records, it does not execute
+        agent._sample_step += self.buffer.T
+        self.global_timestep += self.buffer.T * self.buffer.N
+
     def collect(self):
+        if getattr(self, "_graph", None) is not None:
+            raise RuntimeError("this runner replays a captured rollout graph; call collect_graphed()")
+        self._collect_body()
+        self.global_timestep += self.buffer.T * self.buffer.N
+
+    def _collect_body(self):
         env, agent, buf = self.env, self.agent, self.buffer
         for t in range(buf.T):
             a, logp, v = agent.select_actions(buf.obs[t], buf.legal_masks[t])
@@ -34,15 +69,14 @@ class SelfPlayRunner:
             self.episodes += torch.stack([d.sum(), (d & (w == 0)).sum(), (d & (w == 1)).sum(), (d & (w < 0)).sum()])
         last_values = agent.get_values(buf.obs[buf.T])
         buf.compute_advantages_and_returns(last_values)
-        self.global_timestep += buf.T * buf.N
 
     def update(self):
         metrics = self.agent.learn(self.buffer)
         self.buffer.clear()
         return metrics
 
-    def iteration(self):
-        self.collect()
+    def iteration(self, graphed=False):
+        self.collect_graphed() if graphed else self.collect()
         return self.update()
 
     def episode_stats(self):

@@ -9,8 +9,8 @@ void gae_entry(void *) { ksh_gae_kernel(ga.r, ga.v, ga.d, ga.lv, ga.g, ga.gl, ga
 
 struct SampA { const void *logits; int dtype; const uint8_t *mask; const uint32_t *bits; int B; unsigned long long seed, step; int det; long long *act; float *lp; } sa;
 void samp_entry(void *) {
-    if (sa.dtype == 0) ksh_masked_sample_kernel<float>((const float *)sa.logits, sa.mask, sa.bits, sa.B, sa.seed, sa.step, sa.det, sa.act, sa.lp);
-    else ksh_masked_sample_kernel<ksh_bf16>((const ksh_bf16 *)sa.logits, sa.mask, sa.bits, sa.B, sa.seed, sa.step, sa.det, sa.act, sa.lp);
+    if (sa.dtype == 0) ksh_masked_sample_kernel<float>((const float *)sa.logits, sa.mask, sa.bits, sa.B, sa.seed, sa.step, nullptr, sa.det, sa.act, sa.lp);
+    else ksh_masked_sample_kernel<ksh_bf16>((const ksh_bf16 *)sa.logits, sa.mask, sa.bits, sa.B, sa.seed, sa.step, nullptr, sa.det, sa.act, sa.lp);
 }
 KshLossArgs la;
 const void *l_logits; void *l_dlogits; int l_dtype;

@@ -155,6 +155,39 @@ def test_compact_formats_run_the_same_rollout_and_update():
         assert abs(a["metrics"][k] - b["metrics"][k]) < 1e-4, k
 
 
+def test_graph_captured_rollout_replays_the_eager_rollout():
+    """BASELINE configs[4]: the whole T-step self-play rollout (tower forward in BatchNorm train mode, sampler with a
+    device-side Philox counter, env kernel, bookkeeping, GAE) captured in one hipGraph produces, replay after replay,
+    exactly the trajectories of the eager loop."""
+    from shogidrl_amd.agent import PPOConfig, VecPPOAgent
+    from shogidrl_amd.buffer import VecExperienceBuffer
+    from shogidrl_amd.env import VecShogiEnv
+    from shogidrl_amd.models import ResTowerActorCritic
+    from shogidrl_amd.rollout import SelfPlayRunner
+    N, T = 96, 6
+
+    def make():
+        torch.manual_seed(0)
+        cfg = PPOConfig(seed=11, mixed_precision=True, channels_last=True)
+        agent = VecPPOAgent(ResTowerActorCritic(46, 13527, 2, 32, 0.25), cfg, DEV)
+        return SelfPlayRunner(VecShogiEnv(N, 40, device=DEV), agent, VecExperienceBuffer(T, N, cfg.gamma, cfg.lambda_gae, DEV))
+    eager, graphed = make(), make()
+    for it in range(4):                       # graphed: eager pass, capture + replay, replay, replay
+        eager.collect()
+        graphed.collect_graphed()
+        a, b = eager.buffer, graphed.buffer
+        for name in ("obs", "legal_masks", "actions", "rewards", "dones", "log_probs", "values", "advantages", "returns"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (it, name)
+        assert torch.equal(eager.episodes, graphed.episodes) and eager.global_timestep == graphed.global_timestep
+        for (k, x), (_, y) in zip(eager.agent.model.state_dict().items(), graphed.agent.model.state_dict().items()):
+            assert torch.equal(x, y), (it, k)                         # BatchNorm running statistics advance identically
+        eager.buffer.clear()
+        graphed.buffer.clear()
+    assert graphed._graph is not None and int(graphed.episodes[0]) > 0
+    with pytest.raises(RuntimeError):
+        graphed.collect()
+
+
 def test_reference_style_single_game_calls():
     from shogidrl_amd.agent import VecPPOAgent
     from shogidrl_amd.env import VecShogiEnv
