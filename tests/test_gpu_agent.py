@@ -170,7 +170,7 @@ def test_graph_captured_rollout_replays_the_eager_rollout():
         torch.manual_seed(0)
         cfg = PPOConfig(seed=11, mixed_precision=True, channels_last=True)
         agent = VecPPOAgent(ResTowerActorCritic(46, 13527, 2, 32, 0.25), cfg, DEV)
-        return SelfPlayRunner(VecShogiEnv(N, 40, device=DEV), agent, VecExperienceBuffer(T, N, cfg.gamma, cfg.lambda_gae, DEV))
+        return SelfPlayRunner(VecShogiEnv(N, 16, device=DEV), agent, VecExperienceBuffer(T, N, cfg.gamma, cfg.lambda_gae, DEV))
     eager, graphed = make(), make()
     for it in range(4):                       # graphed: eager pass, capture + replay, replay, replay
         eager.collect()
