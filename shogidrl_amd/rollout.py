@@ -29,6 +29,7 @@ class SelfPlayRunner:
         agent = self.agent
         if getattr(self, "_graph", None) is not None:
             self._graph.replay()
+            self.buffer._advantages_computed = True      # host-side flag the captured GAE call set only once
             agent._sample_step += self.buffer.T
             self.global_timestep += self.buffer.T * self.buffer.N
             return
@@ -45,6 +46,7 @@ class SelfPlayRunner:
         torch.cuda.current_stream().wait_stream(side)
         self._graph = graph
         graph.replay()                     # capture records, it does not execute
+        self.buffer._advantages_computed = True
         agent._sample_step += self.buffer.T
         self.global_timestep += self.buffer.T * self.buffer.N
 

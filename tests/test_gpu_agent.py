@@ -181,6 +181,7 @@ def test_graph_captured_rollout_replays_the_eager_rollout():
         assert torch.equal(eager.episodes, graphed.episodes) and eager.global_timestep == graphed.global_timestep
         for (k, x), (_, y) in zip(eager.agent.model.state_dict().items(), graphed.agent.model.state_dict().items()):
             assert torch.equal(x, y), (it, k)                         # BatchNorm running statistics advance identically
+        assert graphed.buffer.get_batch()["obs"].shape[0] == T * N      # usable by learn() after a replay
         eager.buffer.clear()
         graphed.buffer.clear()
     assert graphed._graph is not None and int(graphed.episodes[0]) > 0
