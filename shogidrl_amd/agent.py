@@ -147,8 +147,9 @@ class VecPPOAgent:
                                            ret.index_select(0, idx), old_values.index_select(0, idx),
                                            cfg.clip_epsilon, cfg.value_loss_coeff, cfg.entropy_coef,
                                            cfg.enable_value_clipping)
-                self.bucket.zero()
+                self.bucket.begin()
                 loss.backward()
+                self.bucket.gather()
                 self.bucket.all_reduce_mean()                      # RCCL over xGMI when world_size > 1
                 flat = self.bucket.flat
                 gnorm = torch.linalg.vector_norm(flat)

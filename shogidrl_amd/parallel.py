@@ -43,14 +43,40 @@ class FlatGradBucket:
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        self.views = []
         off = 0
         for p in self.params:
             # same sizes AND strides as the parameter (channels_last weights keep their layout)
-            p.grad = self.flat[off:off + p.numel()].as_strided(p.size(), p.stride())
+            v = self.flat[off:off + p.numel()].as_strided(p.size(), p.stride())
+            self.views.append(v)
+            p.grad = v
             off += p.numel()
 
     def zero(self):
         self.flat.zero_()
+
+    def begin(self):
+        """Before backward(): drop the .grad views, so that autograd hands each parameter its gradient tensor instead
+        of launching one small `view += grad` kernel per parameter (187 of them for the tower)."""
+        for p in self.params:
+            p.grad = None
+
+    def gather(self):
+        """After backward(): move every gradient into the flat buffer with one multi-tensor copy and point .grad at the
+        views again (the optimizer and the all-reduce work on the flat buffer)."""
+        dst, src = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()                      # parameter not reached by this backward
+            elif p.grad.dtype == v.dtype:
+                dst.append(v)
+                src.append(p.grad)
+            else:
+                v.copy_(p.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def all_reduce_mean(self):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
