@@ -140,6 +140,16 @@ def bn_act(x, bn, residual=None, relu=False, pre_bias=None):
     return y
 
 
+def _tn_matmul(a, b, chunks=32):
+    """a[N,P], b[N,Q] -> a.T @ b [P,Q].  The reduction runs over the batch (N = 4096) while P x Q is tiny, a shape the
+    GEMM library serves with one or two workgroups (58 us); splitting N into `chunks` batched products and summing
+    them keeps the whole chip busy."""
+    N = a.shape[0]
+    if N % chunks or N // chunks < 16:
+        return a.t() @ b
+    return torch.bmm(a.view(chunks, N // chunks, -1).transpose(1, 2), b.view(chunks, N // chunks, -1)).sum(0)
+
+
 class _SETail(torch.autograd.Function):
     """z = relu(x * sigmoid(fc2(relu(fc1(mean_hw(x))))) + r); the two 1x1 convolutions act on [N,C] vectors and are
     evaluated (and differentiated) here as small float32 matrix products."""
@@ -173,10 +183,10 @@ class _SETail(torch.autograd.Function):
               "ksh_se_bwd_reduce")
         with torch.autocast(device_type="cuda", enabled=False):
             du = ds * s * (1.0 - s)                      # through the sigmoid
-            dW2 = du.t() @ h
+            dW2 = _tn_matmul(du, h)
             db2 = du.sum(0)
             dh = (du @ W2) * (h > 0)                     # through the ReLU
-            dW1 = dh.t() @ p
+            dW1 = _tn_matmul(dh, p)
             db1 = dh.sum(0)
             dp = (dh @ W1).contiguous()
         dx = _like(x)
