@@ -112,10 +112,18 @@ class ResTowerActorCritic(nn.Module):
 
     def forward(self, x):
         h = self.trunk(x)
-        # heads in float32 even under bf16 autocast: the logits feed the soft-max / PPO-loss kernels
+        # the 1x1 convolutions that squeeze the trunk to 2 planes follow the ambient autocast (they read the 170 MB
+        # trunk output; in float32 that costs a 340 MB cast and float32 convolutions for 2 output channels); from the
+        # 2-plane features on -- batch norm, ReLU and the Linear layers that produce the logits and the value, which
+        # feed the soft-max / PPO-loss kernels -- everything is float32 even under bf16 autocast
+        p, v = self.policy_head[0](h), self.value_head[0](h)
         with torch.autocast(device_type=x.device.type, enabled=False):
-            h32 = h.float()
-            return self.policy_head(h32), self.value_head(h32).squeeze(-1)
+            p, v = p.float(), v.float()
+            for layer in list(self.policy_head)[1:]:
+                p = layer(p)
+            for layer in list(self.value_head)[1:]:
+                v = layer(v)
+            return p, v.squeeze(-1)
 
 
 def model_factory(model_type, obs_shape=(46, 9, 9), num_actions=NUM_ACTIONS, tower_depth=9, tower_width=256,
