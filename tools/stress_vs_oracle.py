@@ -6,17 +6,21 @@ import time
 import numpy as np
 import torch
 from oracle import ko
+from shogidrl_amd import ops
 from shogidrl_amd.env import VecShogiEnv
 
+COMPACT = len(sys.argv) > 1 and sys.argv[1] == "compact"     # packed masks + bf16 channels-last observations
+
+
 def run(n, steps, max_moves, drop_bias, seed):
-    env = VecShogiEnv(n, max_moves)
+    env = VecShogiEnv(n, max_moves, packed_masks=True, obs_format="bf16_nhwc") if COMPACT else VecShogiEnv(n, max_moves)
     ora = ko.VecGames(n, max_moves)
     env.reset()
     g = torch.Generator(device="cuda:0").manual_seed(seed)
     stats = np.zeros(6, np.int64)
     t0 = time.time()
     for k in range(steps):
-        m = env.legal_mask
+        m = ops.unpack_mask(env.legal_bits) if COMPACT else env.legal_mask
         w = torch.rand(m.shape, device="cuda:0", generator=g) * m
         if drop_bias > 0:
             boost = (torch.rand(n, 1, device="cuda:0", generator=g) < drop_bias).float()
@@ -24,8 +28,13 @@ def run(n, steps, max_moves, drop_bias, seed):
         a = w.argmax(dim=1)
         env.step(a)
         o = ora.step(a.cpu().numpy())
-        assert np.array_equal(env.obs.cpu().numpy(), o[0]), ("obs", k)
-        assert np.array_equal(env.legal_mask.cpu().numpy().astype(np.uint8), o[1]), ("mask", k)
+        if COMPACT:
+            assert env.obs.is_contiguous(memory_format=torch.channels_last)
+            assert torch.equal(env.obs.cpu(), torch.from_numpy(o[0]).to(torch.bfloat16)), ("obs", k)
+            assert np.array_equal(ops.unpack_mask(env.legal_bits).cpu().numpy().astype(np.uint8), o[1]), ("mask", k)
+        else:
+            assert np.array_equal(env.obs.cpu().numpy(), o[0]), ("obs", k)
+            assert np.array_equal(env.legal_mask.cpu().numpy().astype(np.uint8), o[1]), ("mask", k)
         assert np.array_equal(env.reward.cpu().numpy(), o[3]) and np.array_equal(env.done.cpu().numpy().astype(np.uint8), o[4]), ("done", k)
         assert np.array_equal(env.reason.cpu().numpy(), o[5]) and np.array_equal(env.winner.cpu().numpy(), o[6]), ("reason", k)
         for r in range(1, 6):
