@@ -1,0 +1,36 @@
+"""End-to-end sanity run of the whole path at the bench configuration: 4096 self-play games, ResNet 9x256+SE (bf16
+autocast, fused tower glue), T = 32, 10 PPO epochs x minibatch 4096 -- a dozen iterations with the metrics the
+reference logs (ppo/* keys of PPOAgent.learn, episode statistics of StepManager).  Random init, synthetic self-play."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from shogidrl_amd.agent import PPOConfig, VecPPOAgent
+from shogidrl_amd.buffer import VecExperienceBuffer
+from shogidrl_amd.env import VecShogiEnv
+from shogidrl_amd.models import ResTowerActorCritic
+from shogidrl_amd.rollout import SelfPlayRunner
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+torch.backends.cudnn.benchmark = True
+torch.manual_seed(42)
+cfg = PPOConfig(ppo_epochs=10, minibatch_size=4096, mixed_precision=True, channels_last=True, seed=42)
+agent = VecPPOAgent(ResTowerActorCritic(46, 13527, 9, 256, 0.25), cfg, "cuda:0")
+env = VecShogiEnv(4096, 500, device="cuda:0")
+buf = VecExperienceBuffer(32, 4096, cfg.gamma, cfg.lambda_gae, "cuda:0")
+run = SelfPlayRunner(env, agent, buf)
+t0 = time.time()
+for it in range(iters):
+    run.collect_graphed()
+    m = run.update()
+    st = run.episode_stats()
+    print("iter %2d  t=%6.1fs  steps %8d  policy_loss %+.4f  value_loss %.4f  entropy %+.3f  kl %.4f  clip_frac %.3f  "
+          "grad_norm %.3f | episodes %d (black %d / white %d / draws %d)"
+          % (it, time.time() - t0, run.global_timestep, m["ppo/policy_loss"], m["ppo/value_loss"], m["ppo/entropy"],
+             m["ppo/kl_divergence_approx"], m["ppo/clip_fraction"], agent.last_gradient_norm, st["total_episodes_completed"],
+             st["black_wins"], st["white_wins"], st["draws"]), flush=True)
+    assert all(v == v and abs(v) < 1e6 for v in m.values()), "non-finite metric"
+print("ok: %d iterations, %.1f k env-steps/s overall" % (iters, run.global_timestep / (time.time() - t0) / 1e3))
