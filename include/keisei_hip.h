@@ -223,6 +223,21 @@ int ksh_se_bwd_reduce(const void *dy, const void *z, const void *x, int dtype, i
 int ksh_se_bwd_apply(const void *dy, const void *z, const float *scale, const float *dpooled /*dev [N][C]*/, void *dx,
                      void *dresidual, int dtype, int N, int HW, int C, void *stream);
 
+/* bn2 + SE tail of a residual block with two passes merged into their neighbours (training mode):
+ * ksh_bn_pool_fwd_train = ksh_bn_fwd_train without ReLU / residual that also returns pooled[n][c] = mean over HW of y
+ *                         (ksh_se_pool's result) from the same apply pass;
+ * ksh_se_bn_bwd         = ksh_se_bwd_apply whose pass also accumulates the batch-norm backward sums, followed by the
+ *                         batch-norm finalize and apply: dz -> (dresidual, dx of the batch norm's input x, dweight, dbias).
+ *                         dy2: device scratch of the activation's size.  N * HW rows; one block per ceil(N / 1024) samples. */
+int ksh_bn_pool_fwd_train(const void *x, void *y, int dtype, int N, int HW, int C, const float *pre_bias /*or NULL*/,
+                          const float *weight, const float *bias, float *running_mean, float *running_var, float momentum,
+                          float eps, float *save_mean, float *save_invstd, float *pooled /*dev [N][C]*/, void *workspace,
+                          void *stream);
+int ksh_se_bn_bwd(const void *dz, const void *z, const float *scale /*dev [N][C]*/, const float *dpooled /*dev [N][C]*/,
+                  const void *x, void *dy2 /*scratch*/, void *dx, void *dresidual, int dtype, int N, int HW, int C,
+                  const float *weight, const float *save_mean, const float *save_invstd, float *dweight, float *dbias,
+                  void *workspace, void *stream);
+
 /* hipEvent helpers so that host code without a HIP binding (bench.py) can time launches on the very
  * stream they were issued on.  ksh_event_elapsed_ms synchronises on `stop`. */
 int ksh_event_create(void **event);

@@ -21,7 +21,7 @@ SYMBOLS = [
     "ksh_gae_scan", "ksh_ppo_loss_workspace_bytes", "ksh_ppo_loss_fwd_bwd", "ksh_event_create", "ksh_event_record",
     "ksh_event_elapsed_ms", "ksh_event_destroy",
     "ksh_tower_workspace_bytes", "ksh_bn_fwd_train", "ksh_bn_fwd_eval", "ksh_bn_bwd", "ksh_se_pool", "ksh_se_apply",
-    "ksh_se_bwd_reduce", "ksh_se_bwd_apply",
+    "ksh_se_bwd_reduce", "ksh_se_bwd_apply", "ksh_bn_pool_fwd_train", "ksh_se_bn_bwd",
 ]
 
 
@@ -80,6 +80,8 @@ def lib():
     L.ksh_se_apply.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.ksh_se_bwd_reduce.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
     L.ksh_se_bwd_apply.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.ksh_bn_pool_fwd_train.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp]
+    L.ksh_se_bn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.ksh_event_create.argtypes = [C.POINTER(vp)]
     L.ksh_event_record.argtypes = [vp, vp]
     L.ksh_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(f32)]

@@ -496,6 +496,59 @@ int ksh_se_bwd_apply(const void *dy, const void *z, const float *scale, const fl
     return KSH_OK;
 }
 
+// bn2 + SE tail with merged passes (training mode).  Forward part 1: statistics -> finalize -> apply + pool.
+int ksh_bn_pool_fwd_train(const void *x, void *y, int dtype, int N, int HW, int C, const float *pre_bias, const float *weight,
+                          const float *bias, float *running_mean, float *running_var, float momentum, float eps,
+                          float *save_mean, float *save_invstd, float *pooled, void *workspace, void *stream) {
+    if (!se_args_ok("ksh_bn_pool_fwd_train", dtype, N, HW, C)) return KSH_E_ARG;
+    if (!x || !y || !save_mean || !save_invstd || !pooled || !workspace) return fail_arg("ksh_bn_pool_fwd_train: null pointer");
+    if (!aligned16(x) || !aligned16(y)) return fail_arg("ksh_bn_pool_fwd_train: activations must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t M = (int64_t)N * HW;
+    float *partial = (float *)workspace, *coef = partial + (size_t)KSH_TW_MAXG * 2 * C;
+    const KshRowSplit sp = ksh_row_split(M, C, KSH_TW_MAXG);
+    if (dtype == 0) hipLaunchKernelGGL((ksh_bn_stats_kernel<float>), dim3(sp.G), dim3(KSH_TW_THREADS), 0, st, (const float *)x, sp, (const float *)running_mean, pre_bias, partial);
+    else hipLaunchKernelGGL((ksh_bn_stats_kernel<ksh_bf16>), dim3(sp.G), dim3(KSH_TW_THREADS), 0, st, (const ksh_bf16 *)x, sp, (const float *)running_mean, pre_bias, partial);
+    hipLaunchKernelGGL(ksh_bn_finalize_kernel, dim3((C + KSH_TW_FIN_CH - 1) / KSH_TW_FIN_CH), dim3(KSH_TW_THREADS), 0, st,
+                       (const float *)partial, sp, (const float *)running_mean, pre_bias, weight, bias, running_mean, running_var,
+                       momentum, eps, save_mean, save_invstd, coef);
+    if (dtype == 0) hipLaunchKernelGGL((ksh_bn_apply_pool_kernel<float>), dim3(N), dim3(KSH_TW_THREADS), 0, st, (const float *)x, (float *)y, HW, C, (const float *)coef, pooled);
+    else hipLaunchKernelGGL((ksh_bn_apply_pool_kernel<ksh_bf16>), dim3(N), dim3(KSH_TW_THREADS), 0, st, (const ksh_bf16 *)x, (ksh_bf16 *)y, HW, C, (const float *)coef, pooled);
+    HIP_TRY(hipGetLastError());
+    return KSH_OK;
+}
+
+// Backward of the pair: SE backward apply (+ batch-norm partial sums) -> batch-norm finalize -> batch-norm apply.
+// dy2: scratch of the activation's size for the gradient between the two (written, then read).
+int ksh_se_bn_bwd(const void *dz, const void *z, const float *scale, const float *dpooled, const void *x, void *dy2, void *dx,
+                  void *dresidual, int dtype, int N, int HW, int C, const float *weight, const float *save_mean,
+                  const float *save_invstd, float *dweight, float *dbias, void *workspace, void *stream) {
+    if (!se_args_ok("ksh_se_bn_bwd", dtype, N, HW, C)) return KSH_E_ARG;
+    if (!dz || !z || !scale || !dpooled || !x || !dy2 || !dx || !dresidual || !save_mean || !save_invstd || !workspace)
+        return fail_arg("ksh_se_bn_bwd: null pointer");
+    if (!aligned16(dz) || !aligned16(z) || !aligned16(x) || !aligned16(dy2) || !aligned16(dx) || !aligned16(dresidual))
+        return fail_arg("ksh_se_bn_bwd: activations must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t M = (int64_t)N * HW;
+    float *partial = (float *)workspace, *coef = partial + (size_t)KSH_TW_MAXG * 2 * C;
+    const int spb = (N + KSH_TW_MAXG - 1) / KSH_TW_MAXG;          // samples per block: at most KSH_TW_MAXG partial rows
+    KshRowSplit sp;
+    sp.M = M;
+    sp.R = (long long)spb * HW;
+    sp.C = C;
+    sp.G = (N + spb - 1) / spb;
+    const dim3 b(KSH_TW_THREADS);
+    if (dtype == 0) hipLaunchKernelGGL((ksh_se_bwd_apply_bnred_kernel<float>), dim3(sp.G), b, 0, st, (const float *)dz, (const float *)z, scale, dpooled, (const float *)x, save_mean, (float *)dy2, (float *)dresidual, N, HW, C, spb, partial);
+    else hipLaunchKernelGGL((ksh_se_bwd_apply_bnred_kernel<ksh_bf16>), dim3(sp.G), b, 0, st, (const ksh_bf16 *)dz, (const ksh_bf16 *)z, scale, dpooled, (const ksh_bf16 *)x, save_mean, (ksh_bf16 *)dy2, (ksh_bf16 *)dresidual, N, HW, C, spb, partial);
+    hipLaunchKernelGGL(ksh_bn_bwd_finalize_kernel, dim3((C + KSH_TW_FIN_CH - 1) / KSH_TW_FIN_CH), b, 0, st, (const float *)partial, sp,
+                       weight, save_invstd, dweight, dbias, coef);
+    const KshRowSplit sa = ksh_row_split(M, C, 4 * KSH_TW_MAXG);
+    if (dtype == 0) hipLaunchKernelGGL((ksh_bn_bwd_apply_kernel<float, 0, 0>), dim3(sa.G), b, 0, st, (const float *)dy2, (const float *)x, (const float *)nullptr, (float *)dx, (float *)nullptr, sa, save_mean, (const float *)coef);
+    else hipLaunchKernelGGL((ksh_bn_bwd_apply_kernel<ksh_bf16, 0, 0>), dim3(sa.G), b, 0, st, (const ksh_bf16 *)dy2, (const ksh_bf16 *)x, (const ksh_bf16 *)nullptr, (ksh_bf16 *)dx, (ksh_bf16 *)nullptr, sa, save_mean, (const float *)coef);
+    HIP_TRY(hipGetLastError());
+    return KSH_OK;
+}
+
 // ---------------------------------------------------------------------------------- timing helpers
 int ksh_event_create(void **ev) {
     if (!ev) return fail_arg("ksh_event_create: null");

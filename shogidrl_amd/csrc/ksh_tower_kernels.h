@@ -43,8 +43,14 @@ template <> struct KshVec8<ksh_bf16> {
         u.w = (uint32_t)ksh_bf16_bits(v[6]) | ((uint32_t)ksh_bf16_bits(v[7]) << 16);
         *reinterpret_cast<uint4 *>(p) = u;
     }
+    // the values as a store + load round trip would return them
+    static __device__ __forceinline__ void round(float v[8]) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = ksh_u2f((uint32_t)ksh_bf16_bits(v[k]) << 16);
+    }
 };
 template <> struct KshVec8<float> {
+    static __device__ __forceinline__ void round(float *) {}
     static __device__ __forceinline__ void load(const float *p, float v[8]) {
         const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -449,5 +455,107 @@ __global__ void __launch_bounds__(KSH_TW_THREADS) ksh_se_bwd_apply_kernel(const 
         }
         KshVec8<T>::store(dx + off, o);
         KshVec8<T>::store(dr + off, g);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ bn2 + SE tail, merged passes
+// In a residual block with squeeze-excitation the second batch norm feeds the SE tail directly, so two passes can ride
+// on their neighbours: the SE pooling on the batch-norm apply pass (forward), and the batch-norm backward reduction on
+// the SE backward apply pass (which produces the very tensor that reduction would read).
+
+// y = (x - mean) * scale + bias (no ReLU, no residual) AND pooled[n][c] = mean over HW of the stored y; one block per sample
+template <typename T>
+__global__ void __launch_bounds__(KSH_TW_THREADS) ksh_bn_apply_pool_kernel(const T *__restrict__ x, T *__restrict__ y, int HW,
+                                                                           int C, const float *__restrict__ coef /*[3][C]*/,
+                                                                           float *__restrict__ pooled /*[N][C]*/) {
+    __shared__ float red[KSH_TW_THREADS * 16];
+    const int cg = C >> 3, tcg = (int)threadIdx.x % cg, tr = (int)threadIdx.x / cg, rpp = KSH_TW_THREADS / cg;
+    const size_t base = (size_t)blockIdx.x * HW * C;
+    float sc[8], mu[8], bi[8], acc[8], unused[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        sc[k] = coef[tcg * 8 + k];
+        mu[k] = coef[C + tcg * 8 + k];
+        bi[k] = coef[2 * C + tcg * 8 + k];
+        acc[k] = unused[k] = 0.0f;
+    }
+#pragma unroll 4
+    for (int row = tr; row < HW; row += rpp) {
+        const size_t off = base + (size_t)row * C + tcg * 8;
+        float v[8];
+        KshVec8<T>::load(x + off, v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = (v[k] - mu[k]) * sc[k] + bi[k];
+        KshVec8<T>::round(v);                  // the pooled mean is taken over the values as stored (bf16-rounded)
+        KshVec8<T>::store(y + off, v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] += v[k];
+    }
+    ksh_tw_reduce16(red, acc, unused, cg, tcg, tr);
+    if (tr == 0) {
+        const float inv = 1.0f / (float)HW;
+#pragma unroll
+        for (int k = 0; k < 8; k++) pooled[(size_t)blockIdx.x * C + tcg * 8 + k] = acc[k] * inv;
+    }
+}
+
+// SE backward apply (dy2 = dz * (z > 0) * s + dp / HW -> the gradient of the batch norm's output; dr = dz * (z > 0)) that
+// also leaves the batch-norm backward partial sums of dy2 and dy2 * (xc - mean), xc = the batch norm's input.  One block
+// per `spb` samples; partial row b matches KshRowSplit{M = N * HW, R = spb * HW}.
+template <typename T>
+__global__ void __launch_bounds__(KSH_TW_THREADS)
+ksh_se_bwd_apply_bnred_kernel(const T *__restrict__ dz, const T *__restrict__ z, const float *__restrict__ s,
+                              const float *__restrict__ dp, const T *__restrict__ xc, const float *__restrict__ mean,
+                              T *__restrict__ dy2, T *__restrict__ dr, int N, int HW, int C, int spb,
+                              float *__restrict__ partial /*[G][2][C]*/) {
+    __shared__ float red[KSH_TW_THREADS * 16];
+    const int cg = C >> 3, tcg = (int)threadIdx.x % cg, tr = (int)threadIdx.x / cg, rpp = KSH_TW_THREADS / cg;
+    const float inv = 1.0f / (float)HW;
+    float mu[8], a1[8], a2[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        mu[k] = mean[tcg * 8 + k];
+        a1[k] = a2[k] = 0.0f;
+    }
+    const int n0 = (int)blockIdx.x * spb, n1 = n0 + spb < N ? n0 + spb : N;
+    for (int n = n0; n < n1; n++) {
+        const size_t base = (size_t)n * HW * C;
+        float sc[8], add[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            sc[k] = s[(size_t)n * C + tcg * 8 + k];
+            add[k] = dp[(size_t)n * C + tcg * 8 + k] * inv;
+        }
+#pragma unroll 2
+        for (int row = tr; row < HW; row += rpp) {
+            const size_t off = base + (size_t)row * C + tcg * 8;
+            float g[8], o[8], v[8];
+            KshVec8<T>::load(dz + off, g);
+            KshVec8<T>::load(z + off, o);
+            KshVec8<T>::load(xc + off, v);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float dpre = (o[k] > 0.0f) ? g[k] : 0.0f;
+                g[k] = dpre;
+                o[k] = dpre * sc[k] + add[k];
+            }
+            KshVec8<T>::round(o);              // sums over the gradient as stored, like a separate reduction pass would see it
+            KshVec8<T>::store(dr + off, g);
+            KshVec8<T>::store(dy2 + off, o);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                a1[k] += o[k];
+                a2[k] += o[k] * (v[k] - mu[k]);
+            }
+        }
+    }
+    ksh_tw_reduce16(red, a1, a2, cg, tcg, tr);
+    if (tr == 0) {
+        float *o = partial + (size_t)blockIdx.x * 2 * C + tcg * 8;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            o[k] = a1[k];
+            o[C + k] = a2[k];
+        }
     }
 }

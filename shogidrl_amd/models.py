@@ -27,6 +27,7 @@ class TinyActorCritic(nn.Module):
 
 
 FUSED_TOWER_GLUE = True      # False: always take the ATen path (tests compare the two)
+MERGED_BN_SE = True          # False: second batch norm and SE tail as two separate fused nodes
 
 
 class _BN(nn.BatchNorm2d):
@@ -88,7 +89,16 @@ class _Block(nn.Module):
         y = _conv_bn(self.conv1, self.bn1, x, relu=True)
         if self.se is None:
             return _conv_bn(self.conv2, self.bn2, y, residual=x, relu=True)
-        y = _conv_bn(self.conv2, self.bn2, y)
+        if FUSED_TOWER_GLUE and MERGED_BN_SE and y.is_cuda and self.conv2.bias is not None and self.bn2.training:
+            # second batch norm + squeeze-excitation tail as one autograd node (two HBM passes fewer)
+            c = self.conv2
+            h = F.conv2d(y, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
+            z = tower.bn_se_tail(h, self.bn2, self.se, x, c.bias)
+            if z is not None:
+                return z
+            y = self.bn2(h, pre_bias=c.bias)
+        else:
+            y = _conv_bn(self.conv2, self.bn2, y)
         z = tower.se_tail(y, self.se, x) if (FUSED_TOWER_GLUE and y.is_cuda) else None
         return z if z is not None else F.relu(self.se(y) + x)
 

@@ -197,6 +197,83 @@ class _SETail(torch.autograd.Function):
         return dx, dr, dW1.reshape(s1).to(t1), db1.to(tb1), dW2.reshape(s2).to(t2), db2.to(tb2)
 
 
+class _BNSETail(torch.autograd.Function):
+    """z = relu(se(bn(x [+ pre_bias])) + r) in training mode, with the SE pooling riding on the batch-norm apply pass and
+    the batch-norm backward reduction riding on the SE backward apply pass (two HBM passes fewer than bn_act followed
+    by se_tail)."""
+
+    @staticmethod
+    def forward(ctx, x, r, weight, bias, running_mean, running_var, pre_bias, momentum, eps, w1, b1, w2, b2):
+        N, C, H, W = x.shape
+        L = lib()
+        y = _like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        p = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        w = None if weight is None else weight.detach().float().contiguous()
+        b = None if bias is None else bias.detach().float().contiguous()
+        pb = None if pre_bias is None else pre_bias.detach().float().contiguous()
+        check(L.ksh_bn_pool_fwd_train(x.data_ptr(), y.data_ptr(), _code(x), N, H * W, C, _ptr(pb), _ptr(w), _ptr(b),
+                                      _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), mean.data_ptr(),
+                                      invstd.data_ptr(), p.data_ptr(), _workspace(x.device, C).data_ptr(), _stream()),
+              "ksh_bn_pool_fwd_train")
+        with torch.autocast(device_type="cuda", enabled=False):
+            W1 = w1.detach().float().reshape(w1.shape[0], C)
+            W2 = w2.detach().float().reshape(C, w2.shape[1])
+            h = torch.relu(torch.addmm(b1.detach().float(), p, W1.t()))
+            s = torch.sigmoid(torch.addmm(b2.detach().float(), h, W2.t())).contiguous()
+        z = _like(x)
+        check(L.ksh_se_apply(y.data_ptr(), s.data_ptr(), r.data_ptr(), z.data_ptr(), _code(x), N, H * W, C, _stream()),
+              "ksh_se_apply")
+        ctx.save_for_backward(x, y, z, p, h, s, W1, W2, w, mean, invstd)
+        ctx.meta = (weight is not None, bias is not None,
+                    None if pre_bias is None else (pre_bias.shape, pre_bias.dtype),
+                    (w1.shape, w2.shape, w1.dtype, w2.dtype, b1.dtype, b2.dtype))
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, y, z, p, h, s, W1, W2, w, mean, invstd = ctx.saved_tensors
+        has_w, has_b, pbm, (s1, s2, t1, t2, tb1, tb2) = ctx.meta
+        N, C, H, W = x.shape
+        L = lib()
+        dz = _as(dz, x)
+        ds = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        check(L.ksh_se_bwd_reduce(dz.data_ptr(), z.data_ptr(), y.data_ptr(), _code(x), N, H * W, C, ds.data_ptr(), _stream()),
+              "ksh_se_bwd_reduce")
+        with torch.autocast(device_type="cuda", enabled=False):
+            du = ds * s * (1.0 - s)
+            dW2 = _tn_matmul(du, h)
+            db2 = du.sum(0)
+            dh = (du @ W2) * (h > 0)
+            dW1 = _tn_matmul(dh, p)
+            db1 = dh.sum(0)
+            dp = (dh @ W1).contiguous()
+        dy2, dx, dr = _like(x), _like(x), _like(x)
+        dw = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        check(L.ksh_se_bn_bwd(dz.data_ptr(), z.data_ptr(), s.data_ptr(), dp.data_ptr(), x.data_ptr(), dy2.data_ptr(),
+                              dx.data_ptr(), dr.data_ptr(), _code(x), N, H * W, C, _ptr(w), mean.data_ptr(), invstd.data_ptr(),
+                              dw.data_ptr(), db.data_ptr(), _workspace(x.device, C).data_ptr(), _stream()), "ksh_se_bn_bwd")
+        dpb = None if pbm is None else torch.zeros(pbm[0], dtype=pbm[1], device=x.device)
+        return (dx, dr, dw if has_w else None, db if has_b else None, None, None, dpb, None, None,
+                dW1.reshape(s1).to(t1), db1.to(tb1), dW2.reshape(s2).to(t2), db2.to(tb2))
+
+
+def bn_se_tail(x, bn, se, residual, pre_bias=None):
+    """relu(se(bn(x [+ pre_bias])) + residual) with the merged passes; None when not covered (then: bn_act + se_tail)."""
+    if not (supported(x) and supported(residual) and residual.dtype == x.dtype and residual.shape == x.shape):
+        return None
+    if bn.momentum is None or not (bn.training or not bn.track_running_stats):
+        return None
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return _BNSETail.apply(x, residual, bn.weight, bn.bias, rm, rv, pre_bias, bn.momentum, bn.eps, se.fc1.weight,
+                           se.fc1.bias, se.fc2.weight, se.fc2.bias)
+
+
 def se_tail(x, se, residual):
     """relu(se(x) + residual) for the reference's SqueezeExcitation module layout (`se.fc1`, `se.fc2` 1x1 convs);
     None when the tensors are not covered by the fused kernels."""

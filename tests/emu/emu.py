@@ -205,6 +205,8 @@ class EmuTower:
         self.L.emu_se_apply.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32]
         self.L.emu_se_bwd_reduce.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
         self.L.emu_se_bwd_apply.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]
+        self.L.emu_bn_pool_fwd_train.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp]
+        self.L.emu_se_bn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
 
     @staticmethod
     def _in(a, bf16):
@@ -278,3 +280,24 @@ class EmuTower:
         self.L.emu_se_bwd_apply(gi.ctypes.data, zi.ctypes.data, s.ctypes.data, dp.ctypes.data, dx.ctypes.data, dr.ctypes.data,
                                 int(bf16), N, HW, Cn)
         return self._f(dx, bf16), self._f(dr, bf16)
+
+    def bn_pool_fwd_train(self, x, bf16, N, HW, w, b, rm, rv, momentum, eps, pre_bias=None):
+        M, Cn = x.shape
+        p = lambda t: None if t is None else t.ctypes.data
+        xi, y = self._in(x, bf16), self._out(x.shape, bf16)
+        mean, invstd, pooled = np.zeros(Cn, np.float32), np.zeros(Cn, np.float32), np.zeros((N, Cn), np.float32)
+        ws = self._ws(Cn)
+        self.L.emu_bn_pool_fwd_train(p(xi), p(y), int(bf16), N, HW, Cn, p(pre_bias), p(w), p(b), p(rm), p(rv), momentum, eps,
+                                     p(mean), p(invstd), p(pooled), p(ws))
+        return self._f(y, bf16), pooled, rm, rv, mean, invstd
+
+    def se_bn_bwd(self, dz, z, s, dp, x, bf16, N, HW, w, mean, invstd):
+        M, Cn = x.shape
+        p = lambda t: None if t is None else t.ctypes.data
+        gi, zi, xi = self._in(dz, bf16), self._in(z, bf16), self._in(x, bf16)
+        dy2, dx, dr = self._out(x.shape, bf16), self._out(x.shape, bf16), self._out(x.shape, bf16)
+        s, dp = np.ascontiguousarray(s, np.float32), np.ascontiguousarray(dp, np.float32)
+        dw, db, ws = np.zeros(Cn, np.float32), np.zeros(Cn, np.float32), self._ws(Cn)
+        self.L.emu_se_bn_bwd(p(gi), p(zi), p(s), p(dp), p(xi), p(dy2), p(dx), p(dr), int(bf16), N, HW, Cn, p(w), p(mean), p(invstd),
+                             p(dw), p(db), p(ws))
+        return self._f(dx, bf16), self._f(dr, bf16), dw, db

@@ -8,7 +8,7 @@ namespace {
 struct A {
     const void *x, *res, *dy, *y; void *out, *out2; int dtype, relu; KshRowSplit sp; const float *w, *b, *mean, *invstd, *shift;
     float *rm, *rv, *save_mean, *save_invstd, *partial, *coef, *dw, *db; const float *pre_bias; float momentum, eps;
-    int HW, C; const float *s, *dp; float *p;
+    int HW, C, N, spb; const float *s, *dp; float *p;
 } a;
 template <typename T> void stats_t() { ksh_bn_stats_kernel<T>((const T *)a.x, a.sp, a.shift, a.pre_bias, a.partial); }
 void stats_entry(void *) { a.dtype ? stats_t<ksh_bf16>() : stats_t<float>(); }
@@ -43,6 +43,13 @@ template <typename T> void sered_t() { ksh_se_bwd_reduce_kernel<T>((const T *)a.
 void sered_entry(void *) { a.dtype ? sered_t<ksh_bf16>() : sered_t<float>(); }
 template <typename T> void sebap_t() { ksh_se_bwd_apply_kernel<T>((const T *)a.dy, (const T *)a.y, a.s, a.dp, (T *)a.out, (T *)a.out2, a.HW, a.C); }
 void sebap_entry(void *) { a.dtype ? sebap_t<ksh_bf16>() : sebap_t<float>(); }
+template <typename T> void appool_t() { ksh_bn_apply_pool_kernel<T>((const T *)a.x, (T *)a.out, a.HW, a.C, a.coef, a.p); }
+void appool_entry(void *) { a.dtype ? appool_t<ksh_bf16>() : appool_t<float>(); }
+template <typename T> void sebn_t() {
+    ksh_se_bwd_apply_bnred_kernel<T>((const T *)a.dy, (const T *)a.y, a.s, a.dp, (const T *)a.x, a.mean, (T *)a.out, (T *)a.out2, a.N, a.HW,
+                                     a.C, a.spb, a.partial);
+}
+void sebn_entry(void *) { a.dtype ? sebn_t<ksh_bf16>() : sebn_t<float>(); }
 void run(void (*e)(void *), int blocks) { for (int b = 0; b < blocks; b++) emu::run_block(e, nullptr, b, KSH_TW_THREADS); }
 }  // namespace
 
@@ -91,5 +98,32 @@ void emu_se_bwd_apply(const void *dy, const void *z, const float *s, const float
                       int HW, int C) {
     a = A{}; a.dy = dy; a.y = z; a.s = s; a.dp = dp; a.out = dx; a.out2 = dr; a.dtype = dtype; a.HW = HW; a.C = C;
     run(sebap_entry, N);
+}
+void emu_bn_pool_fwd_train(const void *x, void *y, int dtype, int N, int HW, int C, const float *pre_bias, const float *w,
+                           const float *b, float *rm, float *rv, float momentum, float eps, float *save_mean,
+                           float *save_invstd, float *pooled, float *ws) {
+    a = A{};
+    a.x = x; a.out = y; a.dtype = dtype; a.w = w; a.b = b; a.rm = rm; a.rv = rv; a.shift = rm; a.pre_bias = pre_bias;
+    a.momentum = momentum; a.eps = eps; a.save_mean = save_mean; a.save_invstd = save_invstd; a.HW = HW; a.C = C; a.p = pooled;
+    a.partial = ws; a.coef = ws + (size_t)KSH_TW_MAXG * 2 * C;
+    a.sp = ksh_row_split((long long)N * HW, C, KSH_TW_MAXG);
+    run(stats_entry, a.sp.G);
+    run(fin_entry, (C + KSH_TW_FIN_CH - 1) / KSH_TW_FIN_CH);
+    run(appool_entry, N);
+}
+void emu_se_bn_bwd(const void *dz, const void *z, const float *s, const float *dp, const void *x, void *dy2, void *dx, void *dr,
+                   int dtype, int N, int HW, int C, const float *w, const float *mean, const float *invstd, float *dw, float *db,
+                   float *ws) {
+    a = A{};
+    a.dy = dz; a.y = z; a.s = s; a.dp = dp; a.x = x; a.out = dy2; a.out2 = dr; a.dtype = dtype; a.N = N; a.HW = HW; a.C = C;
+    a.mean = mean; a.invstd = invstd; a.w = w; a.dw = dw; a.db = db; a.partial = ws; a.coef = ws + (size_t)KSH_TW_MAXG * 2 * C;
+    a.spb = (N + KSH_TW_MAXG - 1) / KSH_TW_MAXG;
+    a.sp.M = (long long)N * HW; a.sp.R = (long long)a.spb * HW; a.sp.C = C; a.sp.G = (N + a.spb - 1) / a.spb;
+    run(sebn_entry, a.sp.G);
+    run(bfin_entry, (C + KSH_TW_FIN_CH - 1) / KSH_TW_FIN_CH);
+    // batch-norm backward apply on the gradient just produced
+    a.dy = dy2; a.y = nullptr; a.out = dx; a.out2 = nullptr; a.relu = 0;
+    a.sp = ksh_row_split((long long)N * HW, C, 4 * KSH_TW_MAXG);
+    run(bapp_entry, a.sp.G);
 }
 }

@@ -176,3 +176,25 @@ class GpuTower:
         self.check(self.L.ksh_se_bwd_apply(gt.data_ptr(), zt.data_ptr(), st.data_ptr(), dpt.data_ptr(), dx.data_ptr(),
                                            dr.data_ptr(), int(bf16), N, HW, C, self.st()), "ksh_se_bwd_apply")
         return self._np(dx), self._np(dr)
+
+    def bn_pool_fwd_train(self, x, bf16, N, HW, w, b, rm, rv, momentum, eps, pre_bias=None):
+        M, C = x.shape
+        p = lambda t: None if t is None else t.data_ptr()
+        xt = self._t(x, bf16)
+        y = torch.full_like(xt, float("nan"))
+        wt, bt, rmt, rvt, pbt = self._t(w), self._t(b), self._t(rm), self._t(rv), self._t(pre_bias)
+        mean, invstd, pooled, ws = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty((N, C), device=DEV), self._ws(C)
+        self.check(self.L.ksh_bn_pool_fwd_train(p(xt), p(y), int(bf16), N, HW, C, p(pbt), p(wt), p(bt), p(rmt), p(rvt), momentum, eps,
+                                                p(mean), p(invstd), p(pooled), p(ws), self.st()), "ksh_bn_pool_fwd_train")
+        return self._np(y), self._np(pooled), self._np(rmt), self._np(rvt), self._np(mean), self._np(invstd)
+
+    def se_bn_bwd(self, dz, z, s, dp, x, bf16, N, HW, w, mean, invstd):
+        M, C = x.shape
+        p = lambda t: None if t is None else t.data_ptr()
+        gt, zt, xt, st, dpt = self._t(dz, bf16), self._t(z, bf16), self._t(x, bf16), self._t(s), self._t(dp)
+        wt, mt, it = self._t(w), self._t(mean), self._t(invstd)
+        dy2, dx, dr = (torch.full_like(xt, float("nan")) for _ in range(3))
+        dw, db, ws = torch.empty(C, device=DEV), torch.empty(C, device=DEV), self._ws(C)
+        self.check(self.L.ksh_se_bn_bwd(p(gt), p(zt), p(st), p(dpt), p(xt), p(dy2), p(dx), p(dr), int(bf16), N, HW, C, p(wt), p(mt),
+                                        p(it), p(dw), p(db), p(ws), self.st()), "ksh_se_bn_bwd")
+        return self._np(dx), self._np(dr), self._np(dw), self._np(db)

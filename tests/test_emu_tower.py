@@ -35,3 +35,8 @@ def test_emu_bn_eval(be):
 @pytest.mark.parametrize("shape,bf16", [((3, 32, 9, 9), False), ((2, 256, 9, 9), True), ((2, 8, 2, 3), False)])
 def test_emu_se_tail(be, shape, bf16):
     towercheck.check_se(be, shape, bf16, seed=shape[1])
+
+
+@pytest.mark.parametrize("shape,bf16", [((5, 32, 9, 9), False), ((3, 256, 9, 9), True), ((2, 8, 2, 3), False)])
+def test_emu_merged_bn_se_pair(be, shape, bf16):
+    towercheck.check_bn_se(be, shape, bf16, seed=shape[1] + 1)

@@ -41,6 +41,11 @@ def test_gpu_se_tail(be, shape, bf16):
     towercheck.check_se(be, shape, bf16, seed=shape[1])
 
 
+@pytest.mark.parametrize("shape,bf16", [((5, 32, 9, 9), False), ((1500, 256, 9, 9), True), ((2, 8, 2, 3), False)])
+def test_gpu_merged_bn_se_pair(be, shape, bf16):
+    towercheck.check_bn_se(be, shape, bf16, seed=shape[1] + 1)      # 1500 samples: two samples per block (spb = 2)
+
+
 def test_gpu_bad_arguments_are_rejected(be):
     from shogidrl_amd._lib import KeiseiHipError
     x = np.zeros((81, 12), np.float32)                       # C = 12: not a multiple of 8
