@@ -162,7 +162,10 @@ def check_bn_se(be, shape, bf16, seed):
     assert ok.mean() > 0.995
     gtol = dict(rtol=2e-2, atol=3e-2) if bf16 else dict(rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(np.where(ok, _nchw(dr, shape), 0), np.where(ok, tr.grad.numpy(), 0), **gtol)
-    np.testing.assert_allclose(np.where(ok, _nchw(dx, shape), 0), np.where(ok, tx.grad.numpy(), 0), **gtol)
+    # the gradient between the two stages is stored in the activation dtype (as it is between two separate ops): in
+    # bf16 its rounding (|dy2| up to ~4 -> 0.016) times w * invstd (up to ~3) bounds the element-wise error of dx
+    xtol = dict(rtol=2e-2, atol=8e-2) if bf16 else gtol
+    np.testing.assert_allclose(np.where(ok, _nchw(dx, shape), 0), np.where(ok, tx.grad.numpy(), 0), **xtol)
     n = N * H * W
     stol = dict(rtol=2e-2, atol=2e-2 * np.sqrt(n)) if bf16 else dict(rtol=1e-4, atol=1e-4 * np.sqrt(n))
     np.testing.assert_allclose(dw, tw.grad.numpy(), **stol)
