@@ -130,8 +130,11 @@ def check_se(be, shape, bf16, seed):
 
 def check_bn_se(be, shape, bf16, seed):
     """The merged pair: y = bn(x + pb) with pooled = mean_hw(y) from one pass, and the backward of
-    z = relu(y * s + r) (+ a gradient dp reaching the pooled mean) down to dx, dr, dw, db -- against autograd on the same
-    float32 expression with s held fixed (its own gradient path is checked by check_se)."""
+    z = relu(y * s + r) (+ a gradient dp reaching the pooled mean) down to dx, dr, dw, db.  The reference is autograd on
+    the same float32 expressions, staged the way the data is staged: the SE tail is differentiated at the y the kernel
+    stored and its gradient enters the batch-norm backward rounded to the activation dtype (in bf16 a reference that
+    keeps y in float32 flips ReLU decisions of elements within rounding distance of zero, an O(1) change per element
+    that says nothing about the kernels).  s is held fixed; its own gradient path is checked by check_se."""
     N, C, H, W = shape
     rng = np.random.default_rng(seed)
     x = (rng.standard_normal(shape) * rng.uniform(0.5, 2.0, (1, C, 1, 1)) + rng.uniform(-1, 1, (1, C, 1, 1))).astype(np.float32)
@@ -144,28 +147,33 @@ def check_bn_se(be, shape, bf16, seed):
     rm0, rv0 = rng.uniform(-0.2, 0.2, C).astype(np.float32), rng.uniform(0.5, 1.5, C).astype(np.float32)
     if bf16:
         x, r, dz = _bf16_round(x), _bf16_round(r), _bf16_round(dz)
-    tx, tr = torch.tensor(x, requires_grad=True), torch.tensor(r, requires_grad=True)
+    # ---- forward
+    tx = torch.tensor(x, requires_grad=True)
     tw, tb = torch.tensor(w, requires_grad=True), torch.tensor(b, requires_grad=True)
     trm, trv = torch.tensor(rm0.copy()), torch.tensor(rv0.copy())
     ty = F.batch_norm(tx + torch.tensor(pb)[None, :, None, None], trm, trv, tw, tb, True, 0.1, 1e-5)
-    tz = F.relu(ty * torch.tensor(s)[:, :, None, None] + tr)
-    ((tz * torch.tensor(dz)).sum() + (ty.mean(dim=(2, 3)) * torch.tensor(dp)).sum()).backward()
     y, pooled, rm, rv, mean, invstd = be.bn_pool_fwd_train(_nhwc(x), bf16, N, H * W, w, b, rm0.copy(), rv0.copy(), 0.1, 1e-5, pre_bias=pb)
     tol = dict(rtol=1e-2, atol=1e-2) if bf16 else dict(rtol=2e-5, atol=2e-5)
-    np.testing.assert_allclose(_nchw(y, shape), ty.detach().numpy(), **tol)
-    np.testing.assert_allclose(pooled, _nchw(y, shape).mean(axis=(2, 3)), rtol=1e-5, atol=1e-6)     # mean of the stored values
+    y_k = _nchw(y, shape)
+    np.testing.assert_allclose(y_k, ty.detach().numpy(), **tol)
+    np.testing.assert_allclose(pooled, y_k.mean(axis=(2, 3)), rtol=1e-5, atol=1e-6)                 # mean of the stored values
     np.testing.assert_allclose(rm, trm.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(rv, trv.numpy(), rtol=2e-5, atol=1e-6)
+    # ---- SE tail at the stored y
+    ty2, tr = torch.tensor(y_k, requires_grad=True), torch.tensor(r, requires_grad=True)
+    tz = F.relu(ty2 * torch.tensor(s)[:, :, None, None] + tr)
+    ((tz * torch.tensor(dz)).sum() + (ty2.mean(dim=(2, 3)) * torch.tensor(dp)).sum()).backward()
     z = be.se_apply(y, s, _nhwc(r), bf16, N, H * W, C)
+    np.testing.assert_allclose(_nchw(z, shape), tz.detach().numpy(), **(dict(rtol=1e-2, atol=1e-2) if bf16 else dict(rtol=1e-6, atol=1e-6)))
+    dy2_ref = _bf16_round(ty2.grad.numpy()) if bf16 else ty2.grad.numpy()
+    ty.backward(torch.tensor(dy2_ref))
+    # ---- backward of the pair
     dx, dr, dw, db = be.se_bn_bwd(_nhwc(dz), z, s, dp, _nhwc(x), bf16, N, H * W, w, mean, invstd)
-    ok = (tz.detach().numpy() > 0) == (_nchw(z, shape) > 0)
-    assert ok.mean() > 0.995
-    gtol = dict(rtol=2e-2, atol=3e-2) if bf16 else dict(rtol=1e-4, atol=1e-4)
+    ok = (tz.detach().numpy() > 0) == (_nchw(z, shape) > 0)              # ties at exactly zero only
+    assert ok.mean() > 0.9999
+    gtol = dict(rtol=2e-2, atol=2e-2) if bf16 else dict(rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(np.where(ok, _nchw(dr, shape), 0), np.where(ok, tr.grad.numpy(), 0), **gtol)
-    # the gradient between the two stages is stored in the activation dtype (as it is between two separate ops): in
-    # bf16 its rounding (|dy2| up to ~4 -> 0.016) times w * invstd (up to ~3) bounds the element-wise error of dx
-    xtol = dict(rtol=2e-2, atol=8e-2) if bf16 else gtol
-    np.testing.assert_allclose(np.where(ok, _nchw(dx, shape), 0), np.where(ok, tx.grad.numpy(), 0), **xtol)
+    np.testing.assert_allclose(np.where(ok, _nchw(dx, shape), 0), np.where(ok, tx.grad.numpy(), 0), **gtol)
     n = N * H * W
     stol = dict(rtol=2e-2, atol=2e-2 * np.sqrt(n)) if bf16 else dict(rtol=1e-4, atol=1e-4 * np.sqrt(n))
     np.testing.assert_allclose(dw, tw.grad.numpy(), **stol)
