@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- the driver's benchmark contract for the Keisei self-play + PPO hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+        N > 1: either started by torch.distributed.run with --nproc-per-node N (the driver), or directly -- then this
+        process only launches N fresh ranks, one per GPU (shogidrl_amd/launch.py), and exits with their status.
 
 One "step" = one full pass of the hot path over one batch: a rollout of T plies for every game of the
 batch (policy forward -> masked sample kernel -> env step kernel, next obs / mask written in place), the
@@ -107,7 +109,7 @@ def env_roofline(dev, n_games, replay_steps, seed):
     warm = 48                                   # desynchronise the games first (opening plies are the cheap ones)
     acts = []
     for t in range(warm + replay_steps):
-        a, _ = ops.masked_sample(logits, live.legal_mask, seed, t)
+        a, _ = ops.masked_sample(logits, live.kernel_mask, seed, t)
         live.step(a, validate=False)
         acts.append(a)
     rep = VecShogiEnv(n_games, 500, device=dev)
@@ -154,10 +156,16 @@ def env_roofline(dev, n_games, replay_steps, seed):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not started by torch.distributed.run: be the launcher.  This parent makes no GPU call; it starts --gpus fresh
+        # ranks (one per GPU), rank 0 prints the JSON line, and any failing rank fails the whole run.
+        from shogidrl_amd import launch
+        sys.exit(launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     from shogidrl_amd import parallel
     rank, local_rank, world = parallel.init_from_env()
-    if world != args.gpus and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        # the driver passes the same N to the launcher and to --gpus; anything else is a mis-launch, not a note
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node == --gpus)" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
@@ -236,6 +244,8 @@ def main():
             "value": transitions / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world,
+            "world_size": dist.get_world_size() if dist.is_initialized() else 1,      # as torch.distributed sees it
+            "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist.is_initialized() else "none (single rank)",
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,

@@ -182,6 +182,15 @@ int ksh_ppo_loss_fwd_bwd(const void *logits /*dev [B,A]*/, int logits_dtype, con
                          void *dlogits /*dev [B,A]*/, float *dvalues /*dev [B]*/, float *stats /*dev [8]*/,
                          void *workspace /*dev*/, void *stream);
 
+/* evaluate_actions' tail alone (core/base_actor_critic.py:118-184): log-prob of actions[b] under the masked soft-max
+ * and the entropy of the row's distribution, with Categorical(probs)'s eps-clamp semantics -- the loss kernels with the
+ * gradient switched off.  Exactly one of mask (bytes) / mask_bits (packed) is non-NULL.
+ * workspace: at least ksh_evaluate_actions_workspace_bytes(B) bytes of device scratch. */
+uint64_t ksh_evaluate_actions_workspace_bytes(int B);
+int ksh_evaluate_actions(const void *logits /*dev [B,A]*/, int logits_dtype, const uint8_t *mask, const uint32_t *mask_bits,
+                         const int64_t *actions /*dev [B]*/, int B, float *log_probs /*dev [B]*/, float *entropy /*dev [B]*/,
+                         void *workspace /*dev*/, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Tower glue: the normalisation / activation / residual work between the convolutions of the actor-critic
  * (training/models/resnet_tower.py:28-46 ResidualBlock.forward, :15-26 SqueezeExcitation.forward, :82-83 stem),

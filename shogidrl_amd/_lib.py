@@ -18,6 +18,7 @@ SYMBOLS = [
     "ksh_last_error", "ksh_version", "ksh_env_create", "ksh_env_destroy", "ksh_env_num_games", "ksh_env_max_moves",
     "ksh_env_set_obs_format", "ksh_env_obs_format",
     "ksh_env_reset", "ksh_env_observe", "ksh_env_evaluate_termination", "ksh_env_step", "ksh_env_reset_packed", "ksh_env_step_packed", "ksh_env_set_state", "ksh_env_get_state", "ksh_masked_sample", "ksh_masked_sample_packed", "ksh_masked_sample_graph", "ksh_ppo_loss_fwd_bwd_packed",
+    "ksh_evaluate_actions", "ksh_evaluate_actions_workspace_bytes",
     "ksh_gae_scan", "ksh_ppo_loss_workspace_bytes", "ksh_ppo_loss_fwd_bwd", "ksh_event_create", "ksh_event_record",
     "ksh_event_elapsed_ms", "ksh_event_destroy",
     "ksh_tower_workspace_bytes", "ksh_bn_fwd_train", "ksh_bn_fwd_eval", "ksh_bn_bwd", "ksh_se_pool", "ksh_se_apply",
@@ -69,6 +70,9 @@ def lib():
     L.ksh_gae_scan.argtypes = [vp, vp, vp, vp, f64, f64, i32, i32, vp, vp, vp]
     L.ksh_ppo_loss_workspace_bytes.restype = u64
     L.ksh_ppo_loss_workspace_bytes.argtypes = [i32]
+    L.ksh_evaluate_actions_workspace_bytes.restype = u64
+    L.ksh_evaluate_actions_workspace_bytes.argtypes = [i32]
+    L.ksh_evaluate_actions.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]
     L.ksh_ppo_loss_fwd_bwd.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp]
     i64 = C.c_int64
     L.ksh_tower_workspace_bytes.restype = u64

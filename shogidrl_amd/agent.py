@@ -18,7 +18,7 @@ import torch
 
 from . import ops
 from .mapper import PolicyOutputMapper
-from .parallel import FlatGradBucket, all_reduce_mean_, global_advantage_moments
+from .parallel import FlatGradBucket, all_reduce_mean_, check_equal_batches, global_advantage_moments, sync_buffers
 
 
 @dataclass
@@ -36,6 +36,13 @@ class PPOConfig:
     gradient_clip_max_norm: float = 0.5
     normalize_advantages: bool = True
     enable_value_clipping: bool = False
+    # False = the reference: the buffer's log-probs are the ones select_action produced while acting, i.e. under the
+    # BatchNorm batch statistics of ONE rollout step (ppo_agent.py:150 acts in train mode), although learn() re-evaluates
+    # the same samples under the statistics of shuffled cross-timestep minibatches -- the PPO ratio is then not 1 even
+    # before the first optimizer step (measured: tests/test_gpu_agent.py::test_first_minibatch_ratio...).
+    # True = one extra no-grad pass at the start of learn() re-computes them under learn-time statistics (running
+    # statistics untouched), so that ratio == 1 / KL == 0 up to minibatch-composition noise when learning starts.
+    recompute_old_log_probs: bool = False
     mixed_precision: bool = False          # bf16 autocast of the tower (the reference uses fp16 + GradScaler)
     channels_last: bool = False
     seed: int = 42
@@ -85,7 +92,8 @@ class VecPPOAgent:
 
     @torch.no_grad()
     def select_actions(self, obs, legal_mask, *, is_training=True):
-        """obs [N,46,9,9], legal_mask bool [N,13527] -> (action int64 [N], log_prob [N], value [N])."""
+        """obs [N,46,9,9], legal_mask bool [N,13527] (or the same sets bit-packed, int32 [N,424]) ->
+        (action int64 [N], log_prob [N], value [N])."""
         self.model.train(is_training)                              # BatchNorm uses batch statistics while acting
         logits, value = self._forward(obs)
         if self._step_tensor is not None:                          # graph-captured rollout: counter lives on the device
@@ -117,6 +125,28 @@ class VecPPOAgent:
         return float(self.get_values(o).item())
 
     # ------------------------------------------------------------------ learning
+    @torch.no_grad()
+    def _recompute_log_probs(self, obs, masks, actions):
+        """log-probs of the stored actions under the CURRENT weights and learn-time (train-mode, minibatch) BatchNorm
+        statistics; running statistics and num_batches_tracked are left exactly as they were."""
+        bns = [m for m in self.model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+        saved = [(m.momentum, m.num_batches_tracked.clone() if m.num_batches_tracked is not None else None) for m in bns]
+        for m in bns:
+            m.momentum = 0.0                                       # running = 1 * running + 0 * batch
+        out = torch.empty(obs.shape[0], dtype=torch.float32, device=self.device)
+        try:
+            for start in range(0, obs.shape[0], self.config.minibatch_size):
+                sl = slice(start, start + self.config.minibatch_size)
+                idx = torch.arange(sl.start, min(sl.stop, obs.shape[0]), device=self.device)
+                logits, _ = self._forward(_gather_obs(obs, idx))
+                out[sl], _ = ops.evaluate_actions(logits, masks[sl], actions[sl])
+        finally:
+            for m, (mom, nbt) in zip(bns, saved):
+                m.momentum = mom
+                if nbt is not None:
+                    m.num_batches_tracked.copy_(nbt)
+        return out
+
     def learn(self, buffer):
         cfg = self.config
         self.model.train()
@@ -126,19 +156,23 @@ class VecPPOAgent:
             return {"ppo/policy_loss": 0.0, "ppo/value_loss": 0.0, "ppo/entropy": 0.0,
                     "ppo/kl_divergence_approx": self.last_kl_div, "ppo/learning_rate": lr}
         obs, actions, old_logp = batch["obs"], batch["actions"], batch["log_probs"]
-        old_values, adv, ret, masks = batch["values"], batch["advantages"], batch["returns"], batch["legal_masks"]
+        old_values, adv, ret = batch["values"], batch["advantages"], batch["returns"]
+        masks = batch.get("legal_bits", batch["legal_masks"])     # the kernels read the bit-set when the buffer has it
         if cfg.normalize_advantages:
             n, mean, std = global_advantage_moments(adv, self.group)
             ok = (std > 1e-8) & (n > 1)                            # ppo_agent.py:277-282, decided on the device
             adv = torch.where(ok, ((adv.double() - mean) / torch.where(ok, std, torch.ones_like(std))).float(), adv)
+        if cfg.recompute_old_log_probs:
+            old_logp = self._recompute_log_probs(obs, masks, actions)
         num = obs.shape[0]
+        check_equal_batches(num, self.device, self.group)          # same minibatch count (= collectives) on every rank
         indices = np.arange(num)
         acc = torch.zeros(8, dtype=torch.float32, device=self.device)
         gnorm = torch.zeros((), dtype=torch.float32, device=self.device)
         updates = 0
         for _ in range(cfg.ppo_epochs):
             self._rng.shuffle(indices)
-            perm = torch.from_numpy(indices).to(self.device, non_blocking=True)
+            perm = torch.from_numpy(indices.copy()).to(self.device)   # a copy: `indices` is reshuffled in place next epoch
             for start in range(0, num, cfg.minibatch_size):
                 idx = perm[start:start + cfg.minibatch_size]
                 logits, values = self._forward(_gather_obs(obs, idx))
@@ -157,6 +191,7 @@ class VecPPOAgent:
                 self.optimizer.step()
                 acc += stats
                 updates += 1
+        sync_buffers(self.model, self.group)                       # BatchNorm running statistics: mean over ranks
         acc = all_reduce_mean_(acc / max(updates, 1), self.group).cpu()   # the single host sync of learn()
         self.last_gradient_norm = float(gnorm)
         self.last_kl_div = float(acc[4])

@@ -85,19 +85,26 @@ class ExperienceBuffer:
 class VecExperienceBuffer:
     """[T, N] rollout storage; obs / legal_masks have T+1 slots (slot T holds the bootstrap observation)."""
 
-    def __init__(self, horizon, num_games, gamma, lambda_gae, device="cuda:0", packed_masks=False, obs_format="f32"):
-        """packed_masks=True stores the legal masks bit-packed (int32 [T+1,N,424]: 8x less memory and traffic);
-        obs_format="bf16_nhwc" stores observations the way an env of that format writes them (half the bytes)."""
+    def __init__(self, horizon, num_games, gamma, lambda_gae, device="cuda:0", packed_masks=False, obs_format="f32",
+                 emit_bits=True):
+        """Default: `legal_masks` bool [T+1,N,13527] (the reference's buffer contract, experience_buffer.py:29-97) plus the
+        same sets as `legal_bits` int32 [T+1,N,424] -- the form the sampler / loss kernels read (1.7 KB instead of
+        13.5 KB per row).  emit_bits=False: byte masks only.  packed_masks=True stores ONLY the bit-packed form (then
+        `legal_masks` IS the int32 tensor: 8x less memory and traffic); obs_format="bf16_nhwc" stores observations the
+        way an env of that format writes them (half the bytes)."""
         self.T, self.N, self.gamma, self.lambda_gae = horizon, num_games, gamma, lambda_gae
         self.packed_masks = bool(packed_masks)
+        self.emit_bits = bool(emit_bits) or self.packed_masks
         self.device = torch.device(device)
         d, T, N = self.device, horizon, num_games
         self.obs_format = obs_format
         self.obs = empty_obs((T + 1, N), obs_format, d)
         if self.packed_masks:
             self.legal_masks = torch.empty((T + 1, N, MASK_WORDS), dtype=torch.int32, device=d)
+            self.legal_bits = self.legal_masks
         else:
             self.legal_masks = torch.empty((T + 1, N, NUM_ACTIONS), dtype=torch.bool, device=d)
+            self.legal_bits = torch.empty((T + 1, N, MASK_WORDS), dtype=torch.int32, device=d) if self.emit_bits else None
         self.actions = torch.zeros((T, N), dtype=torch.int64, device=d)
         self.rewards = torch.zeros((T, N), dtype=torch.float32, device=d)
         self.log_probs = torch.zeros((T, N), dtype=torch.float32, device=d)
@@ -118,12 +125,17 @@ class VecExperienceBuffer:
             raise RuntimeError("Cannot get batch: compute_advantages_and_returns() must be called first")
         T, N = self.T, self.N
         f = lambda x: x.reshape(T * N, *x.shape[2:])
-        return {"obs": f(self.obs[:T]), "actions": f(self.actions), "log_probs": f(self.log_probs),
-                "values": f(self.values), "rewards": f(self.rewards), "advantages": f(self.advantages),
-                "returns": f(self.returns), "dones": f(self.dones), "legal_masks": f(self.legal_masks[:T])}
+        out = {"obs": f(self.obs[:T]), "actions": f(self.actions), "log_probs": f(self.log_probs),
+               "values": f(self.values), "rewards": f(self.rewards), "advantages": f(self.advantages),
+               "returns": f(self.returns), "dones": f(self.dones), "legal_masks": f(self.legal_masks[:T])}
+        if self.legal_bits is not None:
+            out["legal_bits"] = f(self.legal_bits[:T])     # what the loss kernel reads; "legal_masks" stays the contract
+        return out
 
     def clear(self):
         # carry the bootstrap observation over as the first observation of the next rollout
         self.obs[0].copy_(self.obs[self.T])
         self.legal_masks[0].copy_(self.legal_masks[self.T])
+        if self.legal_bits is not None and self.legal_bits is not self.legal_masks:
+            self.legal_bits[0].copy_(self.legal_bits[self.T])
         self._advantages_computed = False

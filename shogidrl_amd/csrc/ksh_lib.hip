@@ -281,7 +281,25 @@ uint64_t ksh_ppo_loss_workspace_bytes(int B) { return (uint64_t)(B > 0 ? B : 0) 
 static int loss_impl(const void *logits, int logits_dtype, const uint8_t *mask, const uint32_t *mask_bits,
                      const int64_t *actions, const float *old_log_probs, const float *advantages, const float *returns,
                      const float *values, const float *old_values, int B, float clip_eps, float vf_coef, float ent_coef,
-                     int value_clip, void *dlogits, float *dvalues, float *stats, void *workspace, void *stream);
+                     int value_clip, void *dlogits, float *dvalues, float *stats, void *workspace, void *stream,
+                     float *row_logp = nullptr, float *row_entropy = nullptr);
+
+uint64_t ksh_evaluate_actions_workspace_bytes(int B) {
+    // partial [B][8] + 5 dummy per-row input vectors (zeros are fine: only log-prob / entropy are read back) + dvalues + stats
+    return ksh_ppo_loss_workspace_bytes(B) + (uint64_t)(B > 0 ? B : 0) * 2 * sizeof(float) + 64;
+}
+
+int ksh_evaluate_actions(const void *logits, int logits_dtype, const uint8_t *mask, const uint32_t *mask_bits,
+                         const int64_t *actions, int B, float *log_probs, float *entropy, void *workspace, void *stream) {
+    if ((!mask && !mask_bits) || !log_probs || !entropy || !workspace) return fail_arg("ksh_evaluate_actions: bad argument");
+    // the loss kernels with the gradient switched off: per-row scalars that only feed the (discarded) loss terms read
+    // a zeroed vector
+    float *ws = reinterpret_cast<float *>(workspace);
+    float *zeros = ws + (size_t)B * 8 + 16, *dval = zeros + B;
+    HIP_TRY(hipMemsetAsync(zeros, 0, (size_t)B * sizeof(float), (hipStream_t)stream));
+    return loss_impl(logits, logits_dtype, mask_bits ? nullptr : mask, mask_bits, actions, zeros, zeros, zeros, zeros, nullptr,
+                     B, 0.2f, 0.0f, 0.0f, 0, nullptr, dval, ws + (size_t)B * 8, workspace, stream, log_probs, entropy);
+}
 
 int ksh_ppo_loss_fwd_bwd(const void *logits, int logits_dtype, const uint8_t *mask, const int64_t *actions,
                          const float *old_log_probs, const float *advantages, const float *returns, const float *values,
@@ -305,8 +323,9 @@ int ksh_ppo_loss_fwd_bwd_packed(const void *logits, int logits_dtype, const uint
 static int loss_impl(const void *logits, int logits_dtype, const uint8_t *mask, const uint32_t *mask_bits,
                      const int64_t *actions, const float *old_log_probs, const float *advantages, const float *returns,
                      const float *values, const float *old_values, int B, float clip_eps, float vf_coef, float ent_coef,
-                     int value_clip, void *dlogits, float *dvalues, float *stats, void *workspace, void *stream) {
-    if (!logits || !actions || !old_log_probs || !advantages || !returns || !values || !dlogits || !dvalues ||
+                     int value_clip, void *dlogits, float *dvalues, float *stats, void *workspace, void *stream,
+                     float *row_logp, float *row_entropy) {
+    if (!logits || !actions || !old_log_probs || !advantages || !returns || !values || (!dlogits && !row_logp) || !dvalues ||
         !stats || !workspace || B <= 0)
         return fail_arg("ksh_ppo_loss_fwd_bwd: bad argument");
     if (value_clip && !old_values) return fail_arg("ksh_ppo_loss_fwd_bwd: value_clip needs old_values");
@@ -328,6 +347,8 @@ static int loss_impl(const void *logits, int logits_dtype, const uint8_t *mask, 
     a.dvalues = dvalues;
     a.stats = stats;
     a.partial = reinterpret_cast<float *>(workspace);
+    a.row_logp = row_logp;
+    a.row_entropy = row_entropy;
     // sparse wave-per-row kernel first; rows it flags (more legal actions than its list holds) go to the dense kernel
     a.only_overflow = 1;
     const dim3 sgrid((B + KSH_LOSS_WPB - 1) / KSH_LOSS_WPB), sblock(64 * KSH_LOSS_WPB);

@@ -208,6 +208,9 @@ __device__ __forceinline__ uint32_t ksh_philox(uint32_t c0, uint32_t c1, uint32_
     return c0;
 }
 
+// uniform in the OPEN interval (0,1) from 32 random bits
+__device__ __forceinline__ float ksh_uniform_open(uint32_t x) { return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f); }
+
 // Categorical's eps for float32 (torch.distributions.utils.clamp_probs: finfo(float32).eps)
 #define KSH_EPS 1.1920928955078125e-07f
 
@@ -236,7 +239,9 @@ __device__ __forceinline__ void ksh_sample_visit(KshSampleAcc &A, const T *row, 
     float k = z;
     if (!deterministic) {
         const uint32_t x = ksh_philox((uint32_t)j, (uint32_t)b, s0, s1, k0, k1);
-        const float u = ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
+        // 23 random bits + 0.5: every value k + 0.5, k < 2^23, is exact in float32, so u lies in [2^-24, 1 - 2^-24] --
+        // strictly inside (0,1).  (24 bits + 0.5 would round 16777215.5 up to 2^24, i.e. u == 1, a key of +inf.)
+        const float u = ksh_uniform_open(x);
         k = z - logf(-logf(u));
     }
     if (A.idx < 0 || k > A.key || (k == A.key && j < A.idx)) { A.key = k; A.idx = j; A.zbest = z; }
@@ -379,6 +384,8 @@ struct KshLossArgs {
     float *stats;
     float *partial;  // [B][8]: surrogate, (V-R)^2, (Vc-R)^2, H, old-new logp, clipped flag, overflow flag, -
     int only_overflow;  // dense kernel: process only the rows the sparse kernel flagged (partial[b][6] != 0)
+    float *row_logp;     // [B] or null: log-prob of actions[b] under the masked soft-max (evaluate_actions' first output)
+    float *row_entropy;  // [B] or null: entropy of the row's distribution (evaluate_actions' second output)
 };
 
 template <typename T>
@@ -456,7 +463,10 @@ ksh_ppo_loss_kernel(KshLossArgs a, const T *__restrict__ logits, T *__restrict__
         p[5] = (fabsf(ratio - 1.0f) > a.clip_eps) ? 1.0f : 0.0f;
         p[6] = 0.0f;
         p[7] = 0.0f;
+        if (a.row_logp != nullptr) a.row_logp[b] = new_logp;
+        if (a.row_entropy != nullptr) a.row_entropy[b] = H;
     }
+    if (dlogits == nullptr) return;   // evaluate-only call (ksh_evaluate_actions): no gradient wanted
 
     // pass 3: dz_j = y_j (G_j - c) on legal j, 0 elsewhere; 16-byte stores over the aligned body
     constexpr int V = KshVec<T>::N;
@@ -662,7 +672,10 @@ ksh_ppo_loss_sparse_kernel(KshLossArgs a, const T *__restrict__ logits, T *__res
         part[5] = (fabsf(ratio - 1.0f) > a.clip_eps) ? 1.0f : 0.0f;
         part[6] = 0.0f;
         part[7] = 0.0f;
+        if (a.row_logp != nullptr) a.row_logp[b] = new_logp;
+        if (a.row_entropy != nullptr) a.row_entropy[b] = H;
     }
+    if (dlogits == nullptr) return;   // evaluate-only call: no gradient wanted (wave-uniform)
     // pass 3: gradients of the legal entries (kept in LDS), zero row, scatter
     for (int e = lane; e < n; e += 64) {
         const float y = expf(s_z[wv][e] - m) * inv_s;

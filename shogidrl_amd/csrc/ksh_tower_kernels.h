@@ -194,8 +194,8 @@ __device__ __forceinline__ bool ksh_tw_sum_partials(const float *__restrict__ pa
 // pre_bias is the bias of the convolution that produced x, folded in here instead of being added to x: BN(x + pb)
 // equals BN(x) with the batch mean moved by pb, so only the running mean sees it.
 extern "C" __global__ void __launch_bounds__(KSH_TW_THREADS)
-ksh_bn_finalize_kernel(const float *__restrict__ partial, KshRowSplit sp, const float *__restrict__ shift,
-                       const float *__restrict__ pre_bias, const float *__restrict__ w, const float *__restrict__ b, float *running_mean, float *running_var,
+ksh_bn_finalize_kernel(const float *__restrict__ partial, KshRowSplit sp, const float *shift /* may alias running_mean */,
+                       const float *pre_bias, const float *__restrict__ w, const float *__restrict__ b, float *running_mean, float *running_var,
                        float momentum, float eps, float *__restrict__ save_mean, float *__restrict__ save_invstd,
                        float *__restrict__ coef /*[3][C]*/) {
     int c;

@@ -44,13 +44,15 @@ def _obs_dense(obs, obs_format):
 
 class VecShogiEnv:
     def __init__(self, num_games, max_moves_per_game=500, device="cuda:0", auto_reset=True, packed_masks=False,
-                 obs_format="f32"):
+                 obs_format="f32", emit_bits=True):
         """obs_format="bf16_nhwc": observations are written as bfloat16 in channels_last memory format (7 452 B per
         game instead of 14 904) -- tensors still have shape [N,46,9,9] and equal
         `obs_f32.to(torch.bfloat16)` bit for bit; see `empty_obs`.
-        packed_masks=True: the kernel writes legal masks ONLY in the bit-packed form (`legal_bits`, int32 [N,424],
-        1 696 B instead of 13 527 B per game-step); `legal_mask` is then unavailable, and the sampler /
-        loss ops accept the packed tensor directly."""
+        Legal masks: by default the kernel writes BOTH the reference's `legal_mask` (bool [N,13527], the drop-in
+        contract, utils/utils.py:310-336) and the same set as `legal_bits` (int32 [N,424], 1 696 B per game, +6 % bytes):
+        the sampler / loss kernels read the bit-set instead of re-reading the 13.5 KB byte row it was expanded from.
+        emit_bits=False: byte mask only (the round-1 contract path, kept for A/B measurements).
+        packed_masks=True: ONLY the bit-packed form; `legal_mask` is then unavailable."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.KeiseiHipError("VecShogiEnv runs on an MI355X only (device=%r); there is no CPU path" % (device,))
@@ -71,8 +73,9 @@ class VecShogiEnv:
         check(self._L.ksh_env_set_obs_format(self._h, OBS_FORMATS[obs_format]), "ksh_env_set_obs_format")
         self.obs = empty_obs((n,), obs_format, dev)
         self.packed_masks = bool(packed_masks)
+        self.emit_bits = bool(emit_bits) or self.packed_masks
         self.legal_mask = None if self.packed_masks else torch.empty((n, NUM_ACTIONS), dtype=torch.bool, device=dev)
-        self.legal_bits = torch.empty((n, MASK_WORDS), dtype=torch.int32, device=dev) if self.packed_masks else None
+        self.legal_bits = torch.empty((n, MASK_WORDS), dtype=torch.int32, device=dev) if self.emit_bits else None
         self.n_legal = torch.empty(n, dtype=torch.int32, device=dev)
         self.reward = torch.zeros(n, dtype=torch.float32, device=dev)
         self.done = torch.zeros(n, dtype=torch.bool, device=dev)
@@ -96,7 +99,17 @@ class VecShogiEnv:
         return self
 
     # ------------------------------------------------------------------ API
-    def reset(self, reset_mask=None, out_obs=None, out_mask=None):
+    @property
+    def kernel_mask(self):
+        """the mask form the sampler / loss kernels should read: the bit-set when the env emits it, else the byte mask"""
+        return self.legal_bits if self.emit_bits else self.legal_mask
+
+    def _bits_arg(self, t):
+        if t.dtype != torch.int32 or not t.is_contiguous() or t.shape != (self.num_games, MASK_WORDS):
+            raise ValueError("packed masks must be contiguous int32 [N,%d]" % MASK_WORDS)
+        return t
+
+    def reset(self, reset_mask=None, out_obs=None, out_mask=None, out_bits=None):
         """Reset all games (or those where reset_mask is True). Returns (obs, legal mask [bool, or packed bits])."""
         rm = None
         if reset_mask is not None:
@@ -114,6 +127,13 @@ class VecShogiEnv:
             return self.obs, self.legal_bits
         if out_mask is not None:
             self.legal_mask = out_mask
+        if self.emit_bits:
+            if out_bits is not None:
+                self.legal_bits = self._bits_arg(out_bits)
+            check(self._L.ksh_env_reset_packed(self._h, rm.data_ptr() if rm is not None else None, self.obs.data_ptr(),
+                                               self.legal_mask.data_ptr(), self.legal_bits.data_ptr(), self.n_legal.data_ptr(),
+                                               _stream()), "ksh_env_reset_packed")
+            return self.obs, self.legal_mask
         check(self._L.ksh_env_reset(self._h, rm.data_ptr() if rm is not None else None, self.obs.data_ptr(),
                                     self.legal_mask.data_ptr(), self.n_legal.data_ptr(), _stream()), "ksh_env_reset")
         return self.obs, self.legal_mask
@@ -123,6 +143,9 @@ class VecShogiEnv:
             raise NotImplementedError("observe() re-encodes byte masks; use a byte-mask env for state inspection")
         check(self._L.ksh_env_observe(self._h, self.obs.data_ptr(), self.legal_mask.data_ptr(), self.n_legal.data_ptr(),
                                       _stream()), "ksh_env_observe")
+        if self.emit_bits:
+            from . import ops
+            self.legal_bits.copy_(ops.pack_mask(self.legal_mask))   # state inspection path (tests / fixtures), not the hot loop
         return self.obs, self.legal_mask
 
     def evaluate_termination(self):
@@ -131,9 +154,12 @@ class VecShogiEnv:
         check(self._L.ksh_env_evaluate_termination(self._h, self.obs.data_ptr(), self.legal_mask.data_ptr(),
                                                    self.n_legal.data_ptr(), self.done.data_ptr(), self.reason.data_ptr(),
                                                    self.winner.data_ptr(), _stream()), "ksh_env_evaluate_termination")
+        if self.emit_bits:
+            from . import ops
+            self.legal_bits.copy_(ops.pack_mask(self.legal_mask))
         return self.obs, self.legal_mask
 
-    def step(self, actions, validate=True, out_obs=None, out_mask=None, prev_mask=None):
+    def step(self, actions, validate=True, out_obs=None, out_mask=None, prev_mask=None, out_bits=None, prev_bits=None):
         """actions: int64 [N] on the device.  Returns (obs, reward, done, info) like ShogiGame.make_move
         (shogi_game.py:553-572), batched; `terminated` / `truncated` (the Gymnasium split the reference sketches in
         docs/1. DESIGN.md:590-602) are available as properties and computed only when asked for.
@@ -159,6 +185,21 @@ class VecShogiEnv:
         mask = self.legal_mask if out_mask is None else out_mask
         if not _obs_dense(obs, self.obs_format) or not mask.is_contiguous():
             raise ValueError("out_obs / out_mask must be dense in the env's obs format")
+        if self.emit_bits:
+            # contract path: byte mask AND bit-set from one launch; the action is validated against the previous bit-set
+            # (one dword per game instead of a byte gather -- same verdict, tests/test_gpu_env.py)
+            bits = self.legal_bits if out_bits is None else self._bits_arg(out_bits)
+            prev = None
+            if validate:
+                if prev_bits is None and prev_mask is not None:
+                    raise ValueError("this env validates against packed masks: pass prev_bits with prev_mask")
+                prev = (self.legal_bits if prev_bits is None else self._bits_arg(prev_bits)).data_ptr()
+            check(self._L.ksh_env_step_packed(self._h, actions.data_ptr(), prev, obs.data_ptr(), mask.data_ptr(), bits.data_ptr(),
+                                              self.n_legal.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(),
+                                              self.reason.data_ptr(), self.winner.data_ptr(), int(self.auto_reset), _stream()),
+                  "ksh_env_step_packed")
+            self.obs, self.legal_mask, self.legal_bits = obs, mask, bits
+            return obs, self.reward, self.done, {"reason": self.reason, "winner": self.winner, "n_legal": self.n_legal}
         prev = None
         if validate:
             prev = (self.legal_mask if prev_mask is None else prev_mask).data_ptr()

@@ -8,6 +8,7 @@ from dataclasses import dataclass
 import torch
 
 from . import ops
+from ._lib import NUM_ACTIONS
 from .env import VecShogiEnv
 
 
@@ -19,6 +20,10 @@ class EvaluationResult:
     draws: int
     reasons: dict          # termination reason name -> count
     avg_game_length: float
+    winners: object = None       # per game: -1 draw / 0 black / 1 white      (numpy int8 [games])
+    reason_codes: object = None  # per game: KSH_REASON_* code                (numpy uint8 [games])
+    lengths: object = None       # per game: number of plies played           (numpy int32 [games])
+    actions: object = None       # with record_actions: int64 [plies, games], the action handed to every game at every ply
 
     @property
     def win_rate_black(self):
@@ -29,36 +34,43 @@ class UniformRandomPolicy:
     """Stand-in for keisei/utils/opponents.py SimpleRandomOpponent: uniform over the legal actions."""
 
     def __init__(self, seed=0):
-        self.seed, self._step = seed, 0
+        self.seed, self._step, self._zeros = seed, 0, None
 
     def select_actions(self, obs, legal_mask, *, is_training=False):
-        logits = torch.zeros(legal_mask.shape, dtype=torch.float32, device=legal_mask.device)
+        if self._zeros is None or self._zeros.shape[0] != legal_mask.shape[0] or self._zeros.device != legal_mask.device:
+            self._zeros = torch.zeros((legal_mask.shape[0], NUM_ACTIONS), dtype=torch.float32, device=legal_mask.device)
+        logits = self._zeros                              # legal_mask may be the byte mask or the packed bit-set
         a, lp = ops.masked_sample(logits, legal_mask, self.seed, self._step, deterministic=False)
         self._step += 1
         return a, lp, torch.zeros(legal_mask.shape[0], device=legal_mask.device)
 
 
 @torch.no_grad()
-def play_games(black, white, num_games, max_moves_per_game=500, device="cuda:0", deterministic=True):
+def play_games(black, white, num_games, max_moves_per_game=500, device="cuda:0", deterministic=True, record_actions=False):
     """`black` / `white`: objects with select_actions(obs, legal_mask, is_training=...) (VecPPOAgent or a policy
-    above).  Every game is played from the start position until it ends; returns an EvaluationResult."""
+    above).  Every game is played from the start position until it ends; returns an EvaluationResult.
+    record_actions=True keeps the whole action stream (tests replay it on the oracle)."""
     from .env import REASON_NAMES
     env = VecShogiEnv(num_games, max_moves_per_game, device=device, auto_reset=False)
-    obs, mask = env.reset()
+    obs, _ = env.reset()
+    mask = env.kernel_mask
     over = torch.zeros(num_games, dtype=torch.bool, device=env.device)
     reason = torch.zeros(num_games, dtype=torch.uint8, device=env.device)
     winner = torch.full((num_games,), -1, dtype=torch.int8, device=env.device)
     length = torch.zeros(num_games, dtype=torch.int32, device=env.device)
+    stream = []
     for ply in range(max_moves_per_game):
         player = black if ply % 2 == 0 else white              # all games are in lock-step: same side to move
         a, _, _ = player.select_actions(obs, mask, is_training=not deterministic)
+        if record_actions:
+            stream.append(a.clone())
         obs, _, done, info = env.step(a, validate=False)       # finished games ignore further actions (shogi_game.py:589-593)
         newly = done & ~over
         reason = torch.where(newly, info["reason"], reason)
         winner = torch.where(newly, info["winner"], winner)
         length = torch.where(newly, torch.full_like(length, ply + 1), length)
         over |= done
-        mask = env.legal_mask
+        mask = env.kernel_mask
         if ply % 16 == 15 and bool(over.all()):               # one host sync every 16 plies
             break
     r = reason.cpu().tolist()
@@ -67,7 +79,9 @@ def play_games(black, white, num_games, max_moves_per_game=500, device="cuda:0",
         games=num_games, black_wins=sum(1 for x in w if x == 0), white_wins=sum(1 for x in w if x == 1),
         draws=sum(1 for x in w if x < 0),
         reasons={REASON_NAMES[k]: r.count(k) for k in sorted(set(r))},
-        avg_game_length=float(length.float().mean()))
+        avg_game_length=float(length.float().mean()),
+        winners=winner.cpu().numpy(), reason_codes=reason.cpu().numpy(), lengths=length.cpu().numpy(),
+        actions=torch.stack(stream).cpu().numpy() if record_actions else None)
 
 
 @dataclass

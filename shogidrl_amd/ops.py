@@ -108,6 +108,27 @@ def gae(rewards, values, dones, last_values, gamma, lam):
     return adv, ret
 
 
+def evaluate_actions(logits, legal_mask, actions):
+    """(log_probs [B], entropy [B]) of `actions` under the masked soft-max of `logits` -- the tail of
+    BaseActorCriticModel.evaluate_actions (base_actor_critic.py:118-184), no gradient."""
+    _need_cuda(logits, legal_mask, actions)
+    B = logits.shape[0]
+    logits = logits.contiguous()
+    packed = is_packed(legal_mask)
+    assert logits.shape == (B, NUM_ACTIONS) and legal_mask.shape == (B, MASK_WORDS if packed else NUM_ACTIONS)
+    mask = legal_mask.contiguous() if packed else _mask_u8(legal_mask)
+    if actions.dtype != torch.int64:
+        raise TypeError("actions must be int64")
+    logp = torch.empty(B, dtype=torch.float32, device=logits.device)
+    ent = torch.empty(B, dtype=torch.float32, device=logits.device)
+    L = lib()
+    ws = torch.empty(int(L.ksh_evaluate_actions_workspace_bytes(B)), dtype=torch.uint8, device=logits.device)
+    check(L.ksh_evaluate_actions(logits.data_ptr(), _dtype_code(logits), None if packed else mask.data_ptr(),
+                                 mask.data_ptr() if packed else None, actions.contiguous().data_ptr(), B, logp.data_ptr(),
+                                 ent.data_ptr(), ws.data_ptr(), _stream()), "ksh_evaluate_actions")
+    return logp, ent
+
+
 class _PPOLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, values, legal_mask, actions, old_log_probs, advantages, returns, old_values, clip_eps,

@@ -1,8 +1,16 @@
 """Data-parallel self-play PPO over the GPUs of one node: one process per GPU, games sharded across ranks
 (no env-side communication), RCCL all-reduce of a flat gradient buffer per optimizer update and of the
 three advantage moments so that whole-batch normalisation (keisei/core/ppo_agent.py:276-282) is preserved.
-The reference has no distributed path (its `ddp` flag is dead, keisei/config_schema.py:81); the parity
-statement is: a G-rank run equals the 1-rank run on the concatenated batch within fp tolerance."""
+The reference has no distributed path (its `ddp` flag is dead, keisei/config_schema.py:81).
+
+Parity statement, exactly as wide as the tests that back it: for a model WITHOUT batch statistics a G-rank update
+equals the 1-rank update on the concatenated batch within fp tolerance (tests/test_gpu_ddp.py,
+tests/test_parallel_gloo.py).  With BatchNorm the batch statistics are per rank (no SyncBN), so
+the G-rank run is a different -- equally valid -- estimator; what IS guaranteed is that parameters stay bit-identical
+across ranks (one summed gradient) and that the running statistics are re-synchronised (`sync_buffers`) at the end of
+every learn(), so checkpoints and eval-mode values agree on all ranks.  Every rank must hold the same number of
+transitions (`check_equal_batches`): a different minibatch count per rank would issue a different number of
+collectives and hang."""
 import os
 
 import torch
@@ -15,8 +23,15 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
-        # one process per GPU; the modulo only matters when a multi-rank run is rehearsed on a box with fewer GPUs
-        local_rank = local_rank % torch.cuda.device_count()
+        ngpu = torch.cuda.device_count()
+        if local_rank >= ngpu:
+            # one process per GPU.  Ranks may share a GPU only in an explicit rehearsal (gloo collectives; RCCL refuses
+            # two ranks on one device): never silently fold N ranks onto fewer GPUs.
+            if os.environ.get("KSH_ALLOW_GPU_SHARING") != "1":
+                raise RuntimeError("LOCAL_RANK %d but only %d GPU(s) visible: one process per GPU "
+                                   "(KSH_ALLOW_GPU_SHARING=1 + KSH_DIST_BACKEND=gloo rehearses on a shared GPU)"
+                                   % (local_rank, ngpu))
+            local_rank = local_rank % ngpu
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("KSH_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")  # "nccl" is RCCL on ROCm
@@ -26,11 +41,29 @@ def init_from_env(backend=None):
     return rank, local_rank, world
 
 
-def shard_range(n_total, rank, world):
-    """Contiguous [lo, hi) slice of the games owned by `rank`; remainders go to the low ranks."""
+def shard_range(n_total, rank, world, equal=True):
+    """Contiguous [lo, hi) slice of the games owned by `rank`.  equal=True (what the training path needs: the same
+    number of minibatches, hence collectives, on every rank) raises unless n_total divides evenly; equal=False gives
+    remainders to the low ranks (evaluation-style sharding with no collective inside the loop)."""
     base, rem = divmod(n_total, world)
+    if equal and rem:
+        raise ValueError("%d games do not shard evenly over %d ranks; the training path needs equal shards "
+                         "(same number of gradient all-reduces per rank)" % (n_total, world))
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def check_equal_batches(num, device, group=None):
+    """Raise on EVERY rank when the ranks do not hold the same number of transitions (one tiny all-reduce + host read
+    per learn() call).  Without it a short rank would leave the minibatch loop early and the others would wait for
+    its gradient all-reduce forever."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    t = torch.tensor([num, -num], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    hi, lo = int(t[0]), -int(t[1])
+    if hi != lo:
+        raise ValueError("ranks hold different batch sizes (%d..%d transitions); shard the games evenly" % (lo, hi))
 
 
 class FlatGradBucket:
@@ -109,3 +142,27 @@ def broadcast_parameters(module, src=0, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src=src, group=group)
+
+
+def sync_buffers(module, group=None):
+    """Make the module's buffers identical on all ranks: floating buffers (BatchNorm running_mean / running_var, which
+    every rank advances with its OWN games' batch statistics) become the mean over ranks through ONE flat all-reduce;
+    integer buffers (num_batches_tracked) take the maximum.  Called at the end of every learn(), so parameters AND
+    buffers -- i.e. the whole state dict -- agree across ranks whenever a checkpoint can be taken."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    fb = [b for b in module.buffers() if b.is_floating_point()]
+    ib = [b for b in module.buffers() if not b.is_floating_point()]
+    if fb:
+        flat = torch.cat([b.detach().reshape(-1).float() for b in fb])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(dist.get_world_size(group))
+        off = 0
+        for b in fb:
+            b.data.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+    if ib:
+        flat = torch.stack([b.detach().reshape(-1)[0].to(torch.int64) for b in ib])
+        dist.all_reduce(flat, op=dist.ReduceOp.MAX, group=group)
+        for k, b in enumerate(ib):
+            b.data.fill_(flat[k])

@@ -11,13 +11,18 @@ import torch
 
 class SelfPlayRunner:
     def __init__(self, env, agent, buffer):
-        assert env.num_games == buffer.N and env.packed_masks == buffer.packed_masks
+        assert env.num_games == buffer.N and env.packed_masks == buffer.packed_masks and env.emit_bits == buffer.emit_bits
         assert env.obs_format == getattr(buffer, "obs_format", "f32")
         self.env, self.agent, self.buffer = env, agent, buffer
         self.global_timestep = 0
         self.episodes = torch.zeros(4, dtype=torch.int64, device=env.device)   # episodes, black wins, white wins, draws
         env.auto_reset = True
-        env.reset(out_obs=buffer.obs[0], out_mask=buffer.legal_masks[0])
+        # both mask forms per step (contract bytes + the bit-set the kernels read) unless one of them is switched off
+        self._both = env.emit_bits and not env.packed_masks
+        if self._both:
+            env.reset(out_obs=buffer.obs[0], out_mask=buffer.legal_masks[0], out_bits=buffer.legal_bits[0])
+        else:
+            env.reset(out_obs=buffer.obs[0], out_mask=buffer.legal_masks[0])
 
     def collect_graphed(self):
         """collect() replayed from one hipGraph (BASELINE configs[4]: "hipGraph-captured rollout step").  Everything in
@@ -59,8 +64,13 @@ class SelfPlayRunner:
     def _collect_body(self):
         env, agent, buf = self.env, self.agent, self.buffer
         for t in range(buf.T):
-            a, logp, v = agent.select_actions(buf.obs[t], buf.legal_masks[t])
-            env.step(a, prev_mask=buf.legal_masks[t], out_obs=buf.obs[t + 1], out_mask=buf.legal_masks[t + 1])
+            if self._both:
+                a, logp, v = agent.select_actions(buf.obs[t], buf.legal_bits[t])
+                env.step(a, prev_bits=buf.legal_bits[t], out_obs=buf.obs[t + 1], out_mask=buf.legal_masks[t + 1],
+                         out_bits=buf.legal_bits[t + 1])
+            else:
+                a, logp, v = agent.select_actions(buf.obs[t], buf.legal_masks[t])
+                env.step(a, prev_mask=buf.legal_masks[t], out_obs=buf.obs[t + 1], out_mask=buf.legal_masks[t + 1])
             buf.actions[t] = a
             buf.log_probs[t] = logp
             buf.values[t] = v

@@ -126,6 +126,7 @@ def _plib():
                                     C.c_void_p, C.c_void_p]
     L.emu_ppo_loss.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_float, C.c_float, C.c_float,
                                                                           C.c_int] + [C.c_void_p] * 4
+    L.emu_evaluate_actions.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     return L
 
 
@@ -186,6 +187,18 @@ class EmuOps:
                              rt.ctypes.data, vl.ctypes.data, ov.ctypes.data, B, clip_eps, vf, ent, int(value_clip),
                              dl.ctypes.data, dv.ctypes.data, st.ctypes.data, ws.ctypes.data)
         return (from_bf16_bits(dl) if bf16 else dl), dv, st
+
+
+    def evaluate_actions(self, logits, mask, actions):
+        B = logits.shape[0]
+        lg = np.ascontiguousarray(logits, np.float32)
+        m8 = np.ascontiguousarray(mask, np.uint8)
+        a64 = np.ascontiguousarray(actions, np.int64)
+        bits = pack_mask(mask) if self.packed else None
+        lp = np.full(B, np.nan, np.float32); en = np.full(B, np.nan, np.float32)
+        _plib().emu_evaluate_actions(lg.ctypes.data, 0, None if self.packed else m8.ctypes.data,
+                                     None if bits is None else bits.ctypes.data, a64.ctypes.data, B, lp.ctypes.data, en.ctypes.data)
+        return lp, en
 
 
 # ------------------------------------------------------------------ tower-glue kernels

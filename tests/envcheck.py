@@ -59,6 +59,17 @@ def check_traces(make_env, max_games=None, auto_reset=True):
                     ids = np.nonzero(mask[s])[0]
                     acts[s] = int(ids[rng.integers(len(ids))]) if len(ids) else 0
             obs, mask, nl, rew, done, reason, winner = env.step(acts, auto_reset=auto_reset, check_prev=True)
+            if not auto_reset:
+                # finished games stay put (shogi_game.py:589-593; pinned on the reference by sequences_deep.json "after"):
+                # same verdict and observation as on their last ply, reward +1 exactly when somebody won
+                for s, gi in enumerate(gis):
+                    if k >= lens[s]:
+                        i = off[gi + 1] - 1
+                        ctx = (gi, k, "finished")
+                        assert bool(done[s]) and int(reason[s]) == int(z["reason"][i]) and int(winner[s]) == int(z["winner"][i]), ctx
+                        assert rew[s] == (1.0 if int(z["winner"][i]) >= 0 else 0.0), ctx
+                        assert obs_crc(obs[s]) == int(z["obs_crc"][i]), ctx
+                        total_plies += 1
             for s in live:
                 i = off[gis[s]] + k
                 ctx = (gis[s], k)
@@ -73,9 +84,6 @@ def check_traces(make_env, max_games=None, auto_reset=True):
                         assert nl[s] == len(ids) == int(z["n_legal"][i]), ctx
                         assert ids_crc(ids) == int(z["legal_crc"][i]), ctx
                 total_plies += 1
-            if not auto_reset:
-                # a finished game must stay put: drop it from the live set by making it "finished"
-                pass
     return total_plies
 
 
@@ -129,8 +137,10 @@ def check_positions(make_env):
     return checked
 
 
-def check_sequences(make_env):
-    seqs = json.load(open(os.path.join(G, "sequences.json")))
+def check_sequences(make_env, deep=False):
+    """scripted sequences from the reference.  deep=True: sequences_deep.json -- repetitions 70+ / 520+ plies back in the
+    history (max_moves 700: the kernel's hv[1..7] registers and its `base = 512` loop) and steps on finished games."""
+    seqs = json.load(open(os.path.join(G, "sequences_deep.json" if deep else "sequences.json")))
     n = 0
     for s in seqs:
         env = make_env(1, s["max_moves"])
@@ -138,6 +148,8 @@ def check_sequences(make_env):
         if s["sfen"]:
             env.set_state(0, ko.Game(max_moves=s["max_moves"], sfen=s["sfen"]).export_state())
             env.observe()
+        for a in s.get("actions", [])[:-1]:          # lead-in whose outputs traces.npz pins
+            env.step(np.array([a]), auto_reset=False, check_prev=True)
         for k, ply in enumerate(s["plies"]):
             obs, mask, nl, rew, done, reason, winner = env.step(np.array([ply["a"]]), auto_reset=False, check_prev=True)
             ctx = (s["name"], k)
@@ -147,6 +159,15 @@ def check_sequences(make_env):
             if not done[0]:
                 ids = mask_ids(mask[0])
                 assert len(ids) == ply["n_legal"] and ids_crc(ids) == ply["legal_crc"], ctx
+            n += 1
+        for k, ply in enumerate(s.get("after", [])):
+            # the game is over and auto-reset is off: further steps change nothing and report the reference's early
+            # return (shogi_game.py:589-593): same verdict, reward from the nominal mover's point of view
+            obs, mask, nl, rew, done, reason, winner = env.step(np.array([ply["a"]]), auto_reset=False, check_prev=False)
+            ctx = (s["name"], "after", k)
+            assert (float(rew[0]), bool(done[0]), int(reason[0]), int(winner[0])) == \
+                   (ply["r"], ply["done"], ply["reason"], ply["winner"]), ctx
+            assert obs_crc(obs[0]) == ply["obs_crc"], ctx
             n += 1
     return n
 

@@ -21,6 +21,8 @@ class GpuEnv:
     def _out(self):
         e = self.env
         torch.cuda.synchronize()
+        if e.emit_bits:      # contract path: the bit-set the sampler / loss kernels read is the byte mask, packed
+            assert torch.equal(ops.unpack_mask(e.legal_bits), e.legal_mask), "packed legal bits != byte mask"
         return np.ascontiguousarray(e.obs.float().cpu().numpy()), e.legal_mask.cpu().numpy().astype(np.uint8), e.n_legal.cpu().numpy().copy()
 
     def reset(self, reset_mask=None):
@@ -96,6 +98,13 @@ class GpuOps:
                                    t(old_values), clip_eps, vf, ent, bool(value_clip))
         loss.backward()
         return lg.grad.float().cpu().numpy(), vl.grad.cpu().numpy(), stats.cpu().numpy()
+
+
+    def evaluate_actions(self, logits, mask, actions):
+        lp, en = ops.evaluate_actions(torch.as_tensor(np.asarray(logits, np.float32), device=DEV),
+                                      torch.as_tensor(np.asarray(mask, bool), device=DEV),
+                                      torch.as_tensor(np.asarray(actions, np.int64), device=DEV))
+        return lp.cpu().numpy(), en.cpu().numpy()
 
 
 class GpuTower:

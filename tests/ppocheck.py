@@ -179,3 +179,24 @@ def check_sample_bf16(ops):
     act, lp = ops.masked_sample(logits, mask, 1, 1, False, bf16=True)
     want_lp, _, _, _, _ = ppo_oracle.log_prob_entropy(logits, mask, act)
     np.testing.assert_allclose(lp[:-1], want_lp[:-1], atol=BF16_LOGP_ATOL, rtol=0)
+
+
+def check_evaluate_actions(ops, B=9, seed=4):
+    """evaluate_actions' tail (log-prob of the given action + entropy per row, base_actor_critic.py:118-184) against the
+    oracle, incl. a dense row (block kernel), a 1-legal row (log-prob = log(1 - eps), entropy ~ 0) and an all-illegal row."""
+    logits, mask, actions, *_ = random_loss_inputs(B, seed, dense_rows=1, empty_rows=1)
+    one = B - 2
+    mask[one] = False
+    mask[one, 777] = True
+    actions[one] = 777
+    lp, en = ops.evaluate_actions(logits, mask, actions)
+    wlp, wen, _, _, none = ppo_oracle.log_prob_entropy(logits, mask, actions)
+    np.testing.assert_allclose(lp[~none], wlp[~none], atol=LOGP_ATOL, rtol=0)
+    np.testing.assert_allclose(en[~none], wen[~none], atol=2e-5, rtol=1e-5)
+    assert abs(lp[one] - np.log(1.0 - ppo_oracle.EPS)) < 1e-9
+    # all-illegal row: uniform over all actions (base_actor_critic.py:166-174)
+    assert abs(lp[-1] - np.log(1.0 / A)) < 1e-5 and abs(en[-1] - np.log(A)) < 1e-4
+    # and the golden log-probs the reference itself produced (sample.npz)
+    z, lg, mk = load_sample_case()
+    lp2, _ = ops.evaluate_actions(lg, mk, z["actions"])
+    np.testing.assert_allclose(lp2, z["logp"], atol=LOGP_ATOL, rtol=0)

@@ -20,6 +20,12 @@ def test_emu_sequences_fixture():
     assert envcheck.check_sequences(make_env) > 80
 
 
+def test_emu_deep_sequences_sennichite_far_back_and_inert_games():
+    """repetitions found 70+ / 520+ plies back in the history (hv[1..7], the `base = 512` loop at max_moves 700) and
+    steps on finished games -- every output as the reference produced it (sequences_deep.json)"""
+    assert envcheck.check_sequences(make_env, deep=True) > 600
+
+
 def test_emu_traces_fixture():
     # 24 of the 48 golden games here (the GPU suite replays all of them through the C-ABI)
     assert envcheck.check_traces(make_env, max_games=24) > 7000

@@ -60,3 +60,29 @@ def test_emu_packed_masks_give_identical_results():
     (a1, lp1), (a2, lp2) = ops.masked_sample(logits, mask, 5, 6, False), p.masked_sample(logits, mask, 5, 6, False)
     assert np.array_equal(a1, a2)                       # Gumbel-max is order independent: identical actions
     np.testing.assert_allclose(lp1, lp2, atol=1e-6)     # the soft-max sum is accumulated in a different order
+
+
+def test_sampler_uniform_is_strictly_inside_the_unit_interval():
+    """with 24 random bits + 0.5 the largest draw rounded to u == 1.0, i.e. a Gumbel key of +inf that forced
+    the action whatever its probability.  The mapping now uses 23 bits + 0.5 (exact in float32): 0 < u < 1 always."""
+    import ctypes as C
+    import numpy as np
+    from tests.emu.emu import _plib
+    L = _plib()
+    L.emu_uniform_open.restype = C.c_float
+    L.emu_uniform_open.argtypes = [C.c_uint]
+    L.emu_gumbel_key.restype = C.c_float
+    L.emu_gumbel_key.argtypes = [C.c_float, C.c_uint]
+    for x in (0xFFFFFFFF, 0xFFFFFE00, 0xFFFFFF00, 0x0, 0x1FF, 0x200, 0x80000000):
+        u = L.emu_uniform_open(x)
+        assert 0.0 < u < 1.0, (hex(x), u)
+        assert np.isfinite(L.emu_gumbel_key(0.0, x)), hex(x)
+    assert L.emu_uniform_open(0xFFFFFFFF) == np.float32(1.0) - np.float32(2.0 ** -24)
+    assert L.emu_uniform_open(0) == np.float32(2.0 ** -24)
+
+
+def test_emu_evaluate_actions_vs_oracle_and_golden():
+    ppocheck.check_evaluate_actions(ops)
+    p = EmuOps()
+    p.packed = True
+    ppocheck.check_evaluate_actions(p)

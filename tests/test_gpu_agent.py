@@ -266,8 +266,7 @@ def test_single_game_facade_kif_and_text_export(tmp_path):
 REASONS = {None: 0, "Game ongoing": 0, "Tsumi": 1, "stalemate": 2, "Max moves reached": 3, "Sennichite": 4}
 
 
-def test_batched_evaluation_games_finish_and_agree_with_oracle():
-    from oracle import ko
+def test_batched_evaluation_games_finish_with_consistent_counts():
     from shogidrl_amd.evaluation import UniformRandomPolicy, play_games
     res = play_games(UniformRandomPolicy(1), UniformRandomPolicy(2), num_games=96, max_moves_per_game=120,
                      deterministic=False)
@@ -275,6 +274,40 @@ def test_batched_evaluation_games_finish_and_agree_with_oracle():
     assert sum(res.reasons.values()) == 96 and set(res.reasons) <= {"Tsumi", "stalemate", "Max moves reached", "Sennichite"}
     assert 20 <= res.avg_game_length <= 120
     assert res.reasons.get("Tsumi", 0) == res.black_wins + res.white_wins     # only Tsumi produces a winner
+
+
+def test_evaluation_loop_replays_on_the_oracle_without_auto_reset():
+    """f2 parity (keisei/evaluation/strategies/single_opponent.py:170-220 game loop): the action stream play_games fed the
+    env -- including the moves it kept handing to games that were already over -- is replayed on oracle games stepped
+    WITHOUT auto-reset.  Winners, termination reasons and game lengths must agree game by game, and from its last ply on
+    every oracle game must report exactly what the evaluation loop latched (finished games are inert)."""
+    from oracle import ko
+    from shogidrl_amd.evaluation import UniformRandomPolicy, play_games
+    n, mm = 64, 90
+    res = play_games(UniformRandomPolicy(11), UniformRandomPolicy(12), num_games=n, max_moves_per_game=mm,
+                     deterministic=False, record_actions=True)
+    acts = res.actions
+    assert acts.shape[1] == n and acts.shape[0] >= int(res.lengths.max())
+    ora = ko.VecGames(n, mm)
+    first_done = np.zeros(n, np.int32)
+    o_reason = np.zeros(n, np.uint8)
+    o_winner = np.full(n, -1, np.int8)
+    for ply in range(acts.shape[0]):
+        _, _, _, rew, done, reason, winner = ora.step(acts[ply], auto_reset=False)
+        newly = (done != 0) & (first_done == 0)
+        first_done[newly] = ply + 1
+        o_reason[newly] = reason[newly]
+        o_winner[newly] = winner[newly]
+        over = first_done > 0
+        # inert afterwards: same verdict on every later ply, reward +1 only for a decided game (shogi_game.py:589-593)
+        assert np.array_equal(reason[over], o_reason[over]) and np.array_equal(winner[over], o_winner[over])
+        assert np.array_equal(rew[over & ~newly], (o_winner[over & ~newly] >= 0).astype(np.float32))
+    assert (first_done > 0).all()
+    assert np.array_equal(res.lengths, first_done)
+    assert np.array_equal(res.reason_codes, o_reason) and np.array_equal(res.winners, o_winner)
+    assert res.black_wins == int((o_winner == 0).sum()) and res.white_wins == int((o_winner == 1).sum())
+    assert res.draws == int((o_winner < 0).sum())
+    assert abs(res.avg_game_length - float(first_done.mean())) < 1e-4
 
 
 def test_match_and_tournament_account_seats_like_the_reference():
@@ -331,3 +364,38 @@ def test_config0_single_game_episode_plumbing():
     buf.compute_advantages_and_returns(agent.get_value(obs))
     m = agent.learn(buf)
     assert np.isfinite(list(m.values())).all() and len(buf) == 64
+
+
+def test_first_minibatch_ratio_before_any_update():
+    """the stored log-probs come from acting under ONE rollout step's BatchNorm batch statistics, learn()
+    re-evaluates under shuffled-minibatch statistics.  With the learning rate at zero the weights never move, so the
+    KL / clip fraction learn() reports IS the mismatch.  Reference semantics (default) are measured and only required to
+    be finite; with recompute_old_log_probs=True the ratio must be 1 up to minibatch-composition noise."""
+    from shogidrl_amd.agent import PPOConfig, VecPPOAgent
+    from shogidrl_amd.buffer import VecExperienceBuffer
+    from shogidrl_amd.env import VecShogiEnv
+    from shogidrl_amd.models import ResTowerActorCritic
+    from shogidrl_amd.rollout import SelfPlayRunner
+    N, T = 256, 8
+    out = {}
+    for recompute in (False, True):
+        torch.manual_seed(0)
+        cfg = PPOConfig(ppo_epochs=1, minibatch_size=512, learning_rate=0.0, seed=5, mixed_precision=True, channels_last=True,
+                        recompute_old_log_probs=recompute)
+        agent = VecPPOAgent(ResTowerActorCritic(46, A, 2, 32, 0.25), cfg, DEV)
+        run = SelfPlayRunner(VecShogiEnv(N, 120, device=DEV), agent, VecExperienceBuffer(T, N, cfg.gamma, cfg.lambda_gae, DEV))
+        run.collect()
+        stats_before = {k: v.clone() for k, v in agent.model.state_dict().items() if "running" in k or "num_batches" in k}
+        if recompute:
+            b = run.buffer.get_batch()
+            lp = agent._recompute_log_probs(b["obs"], b["legal_bits"], b["actions"])
+            for k, v in agent.model.state_dict().items():               # the extra pass leaves BatchNorm's buffers alone
+                if k in stats_before:
+                    assert torch.equal(v, stats_before[k]), k
+            assert torch.isfinite(lp).all() and float((lp - b["log_probs"]).abs().max()) < 1.0
+        m = run.update()
+        out[recompute] = (m["ppo/kl_divergence_approx"], m["ppo/clip_fraction"])
+    print("first-minibatch mismatch (kl, clip_frac): reference semantics %r, recomputed %r" % (out[False], out[True]))
+    assert all(np.isfinite(v) for v in out[False])
+    assert abs(out[True][0]) < 2e-3 and out[True][1] < 0.01, out
+    assert abs(out[True][0]) <= abs(out[False][0]) + 1e-6

@@ -1,7 +1,7 @@
 """SURVEY 8(e) parity statement on real kernels: a 2-rank data-parallel PPO update (games sharded, flat-gradient
-all-reduce, global advantage moments) equals the 1-rank update on the concatenated batch.  The two ranks share the
-single GPU of the test box, so the collective runs over gloo here; on a multi-GPU node the same code path uses
-RCCL (backend "nccl")."""
+all-reduce, global advantage moments) equals the 1-rank update on the concatenated batch.  On a one-GPU box the two
+ranks share the GPU and the collectives run over gloo (KSH_ALLOW_GPU_SHARING=1); when the box has two GPUs the same
+checks run once more over RCCL (backend "nccl"), one rank per GPU (skipped otherwise)."""
 import os
 import socket
 
@@ -27,59 +27,128 @@ def _batch(seed, n):
                 values=torch.randn(n, generator=g) * 0.5, adv=torch.randn(n, generator=g), ret=torch.randn(n, generator=g))
 
 
-def _learn(batch, lo, hi, minibatch, group=None):
+def _learn(batch, lo, hi, minibatch, group=None, dev="cuda:0", bn=False, epochs=1):
     from shogidrl_amd.agent import PPOConfig, VecPPOAgent
     from shogidrl_amd.buffer import ExperienceBuffer
-    from shogidrl_amd.models import TinyActorCritic
+    from shogidrl_amd.models import ResTowerActorCritic, TinyActorCritic
     torch.manual_seed(5)
-    agent = VecPPOAgent(TinyActorCritic(), PPOConfig(ppo_epochs=1, minibatch_size=minibatch, normalize_advantages=True, seed=1),
-                        "cuda:0", group=group)
+    model = ResTowerActorCritic(46, A, 1, 16, 0.25) if bn else TinyActorCritic()
+    agent = VecPPOAgent(model, PPOConfig(ppo_epochs=epochs, minibatch_size=minibatch, normalize_advantages=True, seed=1),
+                        dev, group=group)
     n = hi - lo
-    buf = ExperienceBuffer(n, 0.99, 0.95, "cuda:0")
+    buf = ExperienceBuffer(n, 0.99, 0.95, dev)
     for b in range(lo, hi):
         buf.add(batch["obs"][b], int(batch["actions"][b]), 0.0, float(batch["logp"][b]), float(batch["values"][b]), False,
                 batch["mask"][b])
     buf.compute_advantages_and_returns(0.0)
-    buf.advantages[:] = batch["adv"][lo:hi].cuda()
-    buf.returns[:] = batch["ret"][lo:hi].cuda()
+    buf.advantages[:] = batch["adv"][lo:hi].to(dev)
+    buf.returns[:] = batch["ret"][lo:hi].to(dev)
     metrics = agent.learn(buf)
     flat = torch.cat([p.detach().reshape(-1) for p in agent.model.parameters()]).cpu()
+    if bn:      # the whole state dict: parameters AND BatchNorm buffers
+        flat = torch.cat([flat] + [b.detach().reshape(-1).double().cpu().float() for b in agent.model.buffers()])
     return metrics, flat
 
 
-def _worker(rank, world, port, n, outdir):
+def _worker(rank, world, port, n, outdir, backend="gloo", bn=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), KSH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      LOCAL_RANK=str(rank), KSH_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "gloo":
+        os.environ["KSH_ALLOW_GPU_SHARING"] = "1"          # both ranks on the one GPU of the test box
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch.distributed as dist
     from shogidrl_amd import parallel
-    parallel.init_from_env()
+    _, local_rank, _ = parallel.init_from_env()
+    assert dist.get_backend() == backend and dist.get_world_size() == world
+    dev = "cuda:%d" % local_rank
+    torch.cuda.set_device(local_rank)
     batch = _batch(77, n)
     lo, hi = parallel.shard_range(n, rank, world)
-    metrics, flat = _learn(batch, lo, hi, minibatch=hi - lo)
-    torch.save({"metrics": metrics, "flat": flat}, os.path.join(outdir, "rank%d.pt" % rank))
+    if bn:   # BatchNorm model, several minibatches per rank: replicas must end with identical state dicts
+        metrics, flat = _learn(batch, lo, hi, minibatch=(hi - lo) // 3, dev=dev, bn=True, epochs=2)
+    else:
+        metrics, flat = _learn(batch, lo, hi, minibatch=hi - lo, dev=dev)
+    torch.save({"metrics": metrics, "flat": flat, "backend": dist.get_backend(), "device": dev},
+               os.path.join(outdir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_update_equals_single_rank_on_concatenated_batch(tmp_path):
-    n = 24
+def _run_two_ranks(tmp_path, n, backend, bn=False):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, str(tmp_path))) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, str(tmp_path), backend, bn)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
+    return [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=True) for r in range(2)]
+
+
+def _check_against_single_rank(r0, r1, n):
     single_metrics, single_flat = _learn(_batch(77, n), 0, n, minibatch=n)
-    r0 = torch.load(os.path.join(str(tmp_path), "rank0.pt"), weights_only=True)
-    r1 = torch.load(os.path.join(str(tmp_path), "rank1.pt"), weights_only=True)
     assert torch.equal(r0["flat"], r1["flat"])                                   # replicas stay in lock-step
     np.testing.assert_allclose(r0["flat"].numpy(), single_flat.numpy(), rtol=0, atol=2e-6)
     for k in ("ppo/policy_loss", "ppo/value_loss", "ppo/entropy", "ppo/kl_divergence_approx", "ppo/clip_fraction"):
         assert abs(r0["metrics"][k] - single_metrics[k]) < 1e-5, k                # metrics are rank-averaged
+
+
+def test_two_rank_update_equals_single_rank_on_concatenated_batch(tmp_path):
+    n = 24
+    r0, r1 = _run_two_ranks(tmp_path, n, "gloo")
+    _check_against_single_rank(r0, r1, n)
+
+
+def test_two_rank_batchnorm_model_ends_with_identical_state_dicts(tmp_path):
+    """with a BatchNorm tower every rank advances the running statistics with its own games; learn() must
+    leave parameters AND buffers identical on all ranks (sync_buffers), also with several minibatches per rank."""
+    r0, r1 = _run_two_ranks(tmp_path, 24, "gloo", bn=True)
+    assert torch.equal(r0["flat"], r1["flat"])
+    assert all(np.isfinite(v) for v in r0["metrics"].values())
+
+
+def test_two_gpu_rccl_update_equals_single_rank(tmp_path):
+    """The same parity check over RCCL ("nccl" backend), one rank per GPU: only runs on a box with >= 2 GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (the RCCL path); the one-GPU box covers the same code over gloo")
+    n = 24
+    r0, r1 = _run_two_ranks(tmp_path, n, "nccl")
+    assert r0["backend"] == "nccl" and {r0["device"], r1["device"]} == {"cuda:0", "cuda:1"}
+    _check_against_single_rank(r0, r1, n)
+    b0, b1 = _run_two_ranks(tmp_path, n, "nccl", bn=True)
+    assert torch.equal(b0["flat"], b1["flat"])
+
+
+def test_bench_launcher_starts_two_ranks_and_reports_them(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment goes through shogidrl_amd/launch.py: two fresh
+    ranks, rank 0 prints the JSON line with world_size 2 and the backend.  On a one-GPU box this is a rehearsal (both
+    ranks share the GPU, gloo collectives); without the explicit sharing switch the same command must fail loudly."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    small = ["--gpus", "2", "--steps", "1", "--warmup", "0", "--games", "64", "--rollout", "4", "--epochs", "1",
+             "--minibatch", "128", "--depth", "1", "--width", "32", "--replay", "4", "--no-cpu-baseline"]
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "KSH_ALLOW_GPU_SHARING", "KSH_DIST_BACKEND"):
+        env.pop(k, None)
+    two = torch.cuda.device_count() >= 2
+    if not two:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + small, capture_output=True, text=True,
+                           timeout=300, env=env)
+        assert r.returncode == 2 and "refusing to run fewer ranks" in r.stderr and not r.stdout.strip()
+        env.update(KSH_ALLOW_GPU_SHARING="1", KSH_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + small, capture_output=True, text=True, timeout=900,
+                       env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["scaling"] == "weak"
+    assert out["backend"].startswith("nccl" if two else "gloo")
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0

@@ -22,6 +22,12 @@ def test_gpu_sequences_fixture(make_env):
     assert envcheck.check_sequences(make_env) > 80
 
 
+def test_gpu_deep_sequences_sennichite_far_back_and_inert_games(make_env):
+    """VERDICT r1 weak 3 + 4: repetitions whose earlier occurrences lie 70+ / 520+ plies back (history registers
+    hv[1..7] and the `base = 512` loop, max_moves 700) and steps on finished games, against reference output"""
+    assert envcheck.check_sequences(make_env, deep=True) > 600
+
+
 def test_gpu_traces_fixture(make_env):
     assert envcheck.check_traces(make_env) > 15000
 
@@ -44,14 +50,17 @@ def test_gpu_random_short_games_many_resets(make_env):
     assert ndone >= 67 * 3
 
 
-def test_gpu_full_size_4096_properties():
-    """BASELINE.json's 4096-game size through size-independent properties: every mask row is a 0/1 row whose
-    population equals n_legal, every observation is a valid one-hot board of the side to move, identical
-    action streams give identical outputs (determinism), and a 64-game sample agrees with the oracle."""
+@pytest.mark.parametrize("N", [4096, 8192])
+def test_gpu_full_size_properties(N):
+    """BASELINE.json's full sizes -- 4096 games (configs[2]/[3]) and 8192 games per GPU (configs[4]: the env kernel's
+    second resident round of waves) -- through size-independent properties: every mask row is a 0/1 row whose
+    population equals n_legal and whose bit-packed twin holds the same set, every observation is a valid one-hot board
+    of the side to move, identical action streams give identical outputs (determinism), and a 64-game sample (the
+    first 32 and the last 32 games of the batch) agrees with the oracle."""
     import torch
     from oracle import ko
+    from shogidrl_amd import ops
     from shogidrl_amd.env import VecShogiEnv
-    N = 4096
     envs = [VecShogiEnv(N, 500), VecShogiEnv(N, 500)]
     for e in envs:
         e.reset()
@@ -62,6 +71,7 @@ def test_gpu_full_size_4096_properties():
         u8 = m.view(torch.uint8)
         assert int(u8.max()) <= 1
         assert torch.equal(u8.sum(dim=1).to(torch.int32), envs[0].n_legal)
+        assert torch.equal(ops.unpack_mask(envs[0].legal_bits), m)          # contract path: bytes and bit-set agree
         w = torch.rand(m.shape, device=m.device, generator=g) * m
         a = w.argmax(dim=1)
         assert bool(m.gather(1, a[:, None]).all())
@@ -73,10 +83,11 @@ def test_gpu_full_size_4096_properties():
         assert bool(((board == 0) | (board == 1)).all())
         assert bool((board.sum(dim=1) <= 1).all())              # at most one piece per square
         assert bool((obs[:, 44:] == 0).all())
-        o = ora.step(a[:64].cpu().numpy(), auto_reset=True)
-        assert np.array_equal(obs[:64].cpu().numpy(), o[0])
-        assert np.array_equal(envs[0].legal_mask[:64].cpu().numpy().astype(np.uint8), o[1])
-        assert np.array_equal(envs[0].done[:64].cpu().numpy().astype(np.uint8), o[4])
+        pick = torch.cat([torch.arange(32), torch.arange(N - 32, N)]).to(a.device)
+        o = ora.step(a[pick].cpu().numpy(), auto_reset=True)
+        assert np.array_equal(obs[pick].cpu().numpy(), o[0])
+        assert np.array_equal(envs[0].legal_mask[pick].cpu().numpy().astype(np.uint8), o[1])
+        assert np.array_equal(envs[0].done[pick].cpu().numpy().astype(np.uint8), o[4])
 
 
 def test_gpu_outputs_at_every_alignment_phase():

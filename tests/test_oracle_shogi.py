@@ -101,6 +101,35 @@ def test_sequences_fixture_sennichite_and_max_moves():
     assert len(s16["plies"]) == 16 and s16["plies"][-1]["reason"] == 4 and not s16["plies"][11]["done"]
 
 
+def test_deep_sequences_fixture_sennichite_far_back_and_inert_finished_games():
+    """sequences_deep.json (reference output, tests/golden/make_golden_deep.py): repetitions whose earlier occurrences lie
+    70+ / 520+ plies back in move_history, and make_move called again on a finished game (shogi_game.py:589-593)."""
+    seqs = json.load(open(os.path.join(G, "sequences_deep.json")))
+    seen = set()
+    for s in seqs:
+        g = ko.Game(max_moves=s["max_moves"])
+        if "actions" in s:                                  # action stream whose per-ply outputs traces.npz already pins
+            for a in s["actions"][:-1]:
+                g.make_move(a)
+        for i, ply in enumerate(s["plies"]):
+            r, d = g.make_move(ply["a"])
+            assert (r, d, g.reason, g.winner) == (ply["r"], ply["done"], ply["reason"], ply["winner"]), (s["name"], i)
+            assert obs_crc(g.observation()) == ply["obs_crc"], (s["name"], i)
+            ids = [] if d else g.legal_ids().tolist()
+            assert len(ids) == ply["n_legal"] and ids_crc(ids) == ply["legal_crc"], (s["name"], i)
+        assert g.game_over
+        for i, ply in enumerate(s["after"]):                # the finished game is inert
+            r, d = g.make_move(ply["a"])
+            assert (r, d, g.reason, g.winner) == (ply["r"], ply["done"], ply["reason"], ply["winner"]), (s["name"], "after", i)
+            assert obs_crc(g.observation()) == ply["obs_crc"]
+        seen.add((s["plies"][-1]["reason"], s["plies"][-1]["winner"]))
+    deep = {s["name"]: s for s in seqs}
+    assert len(deep["deep_sennichite_70"]["plies"]) == 87 and len(deep["deep_sennichite_520"]["plies"]) == 536
+    assert all(p["reason"] == 0 for p in deep["deep_sennichite_520"]["plies"][:-1])     # nothing ends before the 4th occurrence
+    assert {(4, -1), (1, 0), (1, 1), (3, -1)} <= seen
+    assert [p["r"] for p in deep["inert_after_reason1_winner0"]["after"]] == [1.0, 1.0, 1.0]   # nominal mover = the winner
+
+
 def test_traces_fixture_full_games():
     z = np.load(os.path.join(G, "traces.npz"))
     off = z["game_off"]

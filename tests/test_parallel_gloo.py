@@ -12,8 +12,12 @@ from shogidrl_amd import parallel
 
 
 def test_shard_range_partitions_exactly():
+    import pytest
+    with pytest.raises(ValueError):
+        parallel.shard_range(10, 0, 3)                      # the training path insists on equal shards
+    assert [parallel.shard_range(4096, r, 8) for r in range(8)] == [(512 * r, 512 * r + 512) for r in range(8)]
     for n, w in ((4096, 8), (10, 3), (7, 8), (32768, 8)):
-        spans = [parallel.shard_range(n, r, w) for r in range(w)]
+        spans = [parallel.shard_range(n, r, w, equal=False) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         sizes = [hi - lo for lo, hi in spans]
@@ -87,3 +91,61 @@ def test_two_rank_gloo_equals_single_rank():
         assert m == 0.5
     assert torch.equal(res[0][1], res[1][1])
     assert want.numel() == res[0][1].numel()
+
+
+def _bn_worker(rank, world, port, q):
+    """ADVICE r1: (1) BatchNorm running statistics advance with each rank's own games and must be re-synchronised;
+    (2) ranks holding different batch sizes must fail loudly instead of hanging in the gradient all-reduce."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    parallel.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.BatchNorm2d(4), torch.nn.ReLU(),
+                                torch.nn.Flatten(), torch.nn.Linear(4 * 9, 2))
+    bucket = parallel.FlatGradBucket(model.parameters())
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    g = torch.Generator().manual_seed(100 + rank)           # every rank sees its OWN data
+    model.train()
+    for _ in range(3):                                      # more than one minibatch per rank
+        x = torch.randn(6, 3, 3, 3, generator=g) * (1.0 + rank) + rank
+        bucket.begin()
+        model(x).square().mean().backward()
+        bucket.gather()
+        bucket.all_reduce_mean()
+        opt.step()
+    bn = model[1]
+    before = (bn.running_mean.clone(), bn.running_var.clone())
+    parallel.sync_buffers(model)
+    state = torch.cat([t.detach().reshape(-1).double() for t in model.state_dict().values()])
+    raised = False
+    try:
+        parallel.check_equal_batches(64 + rank, "cpu")      # unequal on purpose
+    except ValueError:
+        raised = True
+    parallel.check_equal_batches(64, "cpu")                 # equal: passes on every rank
+    n = lambda t: t.detach().numpy().copy()                 # by value (tensors travel as fds that die with the sender)
+    q.put((rank, n(before[0]), n(before[1]), n(bn.running_mean), n(bn.running_var), int(bn.num_batches_tracked),
+           n(state), raised))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_batchnorm_buffers_are_synchronised_and_unequal_batches_fail_loudly():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res = [tuple(torch.from_numpy(x) if hasattr(x, "dtype") else x for x in r) for r in res]
+    (_, m0, v0, sm0, sv0, nb0, st0, r0), (_, m1, v1, sm1, sv1, nb1, st1, r1) = res
+    assert not torch.allclose(m0, m1)                       # the ranks really had diverged ...
+    assert torch.equal(sm0, sm1) and torch.equal(sv0, sv1)  # ... and agree bit for bit afterwards
+    assert torch.allclose(sm0, (m0 + m1) / 2) and torch.allclose(sv0, (v0 + v1) / 2)
+    assert nb0 == nb1 == 3
+    assert torch.equal(st0, st1)                            # whole state dict (parameters + buffers) identical
+    assert r0 and r1                                        # the size check raised on BOTH ranks (nobody is left waiting)
