@@ -192,6 +192,41 @@ int ksh_evaluate_actions(const void *logits /*dev [B,A]*/, int logits_dtype, con
                          void *workspace /*dev*/, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused policy head.  Replaces the LAST LAYER of the actor-critic's policy head together with the tail that consumes
+ * its output, so that logits [B,13527] (and, in the backward, dlogits) never exist in memory:
+ *   nn.Linear(2*9*9, 13527)                               training/models/resnet_tower.py:63-69
+ *   (nn.Linear(16*9*9, 13527) of the tiny CNN             core/neural_network.py:17)
+ *   + get_action_and_value's tail                         core/base_actor_critic.py:64-116   -> ksh_policy_head_sample
+ *   + evaluate_actions' tail                              core/base_actor_critic.py:139-184  -> ksh_policy_head_evaluate
+ *   + PPOAgent.learn's loss lines and their autograd      core/ppo_agent.py:340-383          -> ksh_policy_head_loss_fwd_bwd
+ * feat  float32 [B,K]  the Linear layer's input (K even, <= 1312; 162 for the ResNet tower), 8-byte aligned
+ * W     float32 [13527,K] = nn.Linear.weight,  bias float32 [13527] (or NULL) = nn.Linear.bias
+ * mask_bits uint32 [B,424]  packed legal masks (KSH_MASK_WORDS; ksh_pack_mask converts bool[13527] rows)
+ * Sparse rows (<= 1024 legal actions; a Shogi position has at most 593) gather only the legal rows of W; rows with
+ * more legal actions (hand-made masks) go through float32 MFMA GEMMs -- set dense_rows_possible = 0 only when the
+ * masks come from the env kernel: the dense path's launches and scratch are then skipped, and a dense row, should one
+ * appear anyway, turns stats / dvalues into NaN instead of being silently mis-evaluated.
+ * Semantics, RNG and stats[8] are those of ksh_masked_sample / ksh_ppo_loss_fwd_bwd with logits = feat W^T + bias;
+ * outputs dfeat [B,K], dW [13527,K], dbias [13527] (or NULL), dvalues [B] are the gradients of `loss`.
+ * workspace: 256-byte aligned device scratch of ksh_policy_head_workspace_bytes (loss) /
+ * ksh_policy_head_evaluate_workspace_bytes (evaluate) bytes.
+ * ---------------------------------------------------------------------------------------------- */
+int ksh_pack_mask(const uint8_t *mask /*dev [B,13527]*/, int B, uint32_t *mask_bits /*dev [B,424]*/, void *stream);
+int ksh_policy_head_sample(const float *feat, const float *W, const float *bias, int K, const uint32_t *mask_bits, int B,
+                           uint64_t seed, uint64_t step, const uint64_t *step_counter /*dev or NULL: added to step*/,
+                           int deterministic, int64_t *action /*dev [B]*/, float *log_prob /*dev [B]*/, void *stream);
+uint64_t ksh_policy_head_evaluate_workspace_bytes(int B, int K, int dense_rows_possible);
+int ksh_policy_head_evaluate(const float *feat, const float *W, const float *bias, int K, const uint32_t *mask_bits,
+                             const int64_t *actions, int B, int dense_rows_possible, float *log_probs /*dev [B]*/,
+                             float *entropy /*dev [B]*/, void *workspace, void *stream);
+uint64_t ksh_policy_head_workspace_bytes(int B, int K, int dense_rows_possible);
+int ksh_policy_head_loss_fwd_bwd(const float *feat, const float *W, const float *bias, int K, const uint32_t *mask_bits,
+                                 const int64_t *actions, const float *old_log_probs, const float *advantages,
+                                 const float *returns, const float *values, const float *old_values, int B, float clip_eps,
+                                 float vf_coef, float ent_coef, int value_clip, int dense_rows_possible, float *dfeat, float *dW,
+                                 float *dbias, float *dvalues, float *stats, void *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Tower glue: the normalisation / activation / residual work between the convolutions of the actor-critic
  * (training/models/resnet_tower.py:28-46 ResidualBlock.forward, :15-26 SqueezeExcitation.forward, :82-83 stem),
  * fused; the convolutions and linear layers themselves stay in PyTorch-ROCm.  Activations are channels-last:

@@ -19,6 +19,8 @@ SYMBOLS = [
     "ksh_env_set_obs_format", "ksh_env_obs_format",
     "ksh_env_reset", "ksh_env_observe", "ksh_env_evaluate_termination", "ksh_env_step", "ksh_env_reset_packed", "ksh_env_step_packed", "ksh_env_set_state", "ksh_env_get_state", "ksh_masked_sample", "ksh_masked_sample_packed", "ksh_masked_sample_graph", "ksh_ppo_loss_fwd_bwd_packed",
     "ksh_evaluate_actions", "ksh_evaluate_actions_workspace_bytes",
+    "ksh_pack_mask", "ksh_policy_head_sample", "ksh_policy_head_evaluate", "ksh_policy_head_evaluate_workspace_bytes",
+    "ksh_policy_head_workspace_bytes", "ksh_policy_head_loss_fwd_bwd",
     "ksh_gae_scan", "ksh_ppo_loss_workspace_bytes", "ksh_ppo_loss_fwd_bwd", "ksh_event_create", "ksh_event_record",
     "ksh_event_elapsed_ms", "ksh_event_destroy",
     "ksh_tower_workspace_bytes", "ksh_bn_fwd_train", "ksh_bn_fwd_eval", "ksh_bn_bwd", "ksh_se_pool", "ksh_se_apply",
@@ -73,6 +75,15 @@ def lib():
     L.ksh_evaluate_actions_workspace_bytes.restype = u64
     L.ksh_evaluate_actions_workspace_bytes.argtypes = [i32]
     L.ksh_evaluate_actions.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]
+    L.ksh_pack_mask.argtypes = [vp, i32, vp, vp]
+    L.ksh_policy_head_sample.argtypes = [vp, vp, vp, i32, vp, i32, u64, u64, vp, i32, vp, vp, vp]
+    L.ksh_policy_head_evaluate_workspace_bytes.restype = u64
+    L.ksh_policy_head_evaluate_workspace_bytes.argtypes = [i32, i32, i32]
+    L.ksh_policy_head_evaluate.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp]
+    L.ksh_policy_head_workspace_bytes.restype = u64
+    L.ksh_policy_head_workspace_bytes.argtypes = [i32, i32, i32]
+    L.ksh_policy_head_loss_fwd_bwd.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, i32, i32,
+                                               vp, vp, vp, vp, vp, vp, vp]
     L.ksh_ppo_loss_fwd_bwd.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp]
     i64 = C.c_int64
     L.ksh_tower_workspace_bytes.restype = u64

@@ -12,6 +12,7 @@ log-prob, entropy, the PPO loss and its gradient) runs in the HIP kernels of sho
 reference there are no per-step `.item()` host syncs: metrics accumulate on the device and are read once
 per learn() call."""
 from dataclasses import dataclass
+from typing import Optional
 
 import numpy as np
 import torch
@@ -36,13 +37,22 @@ class PPOConfig:
     gradient_clip_max_norm: float = 0.5
     normalize_advantages: bool = True
     enable_value_clipping: bool = False
-    # False = the reference: the buffer's log-probs are the ones select_action produced while acting, i.e. under the
-    # BatchNorm batch statistics of ONE rollout step (ppo_agent.py:150 acts in train mode), although learn() re-evaluates
-    # the same samples under the statistics of shuffled cross-timestep minibatches -- the PPO ratio is then not 1 even
-    # before the first optimizer step (measured: tests/test_gpu_agent.py::test_first_minibatch_ratio...).
-    # True = one extra no-grad pass at the start of learn() re-computes them under learn-time statistics (running
-    # statistics untouched), so that ratio == 1 / KL == 0 up to minibatch-composition noise when learning starts.
-    recompute_old_log_probs: bool = False
+    # Which log-probs are "old" in the PPO ratio.
+    #   False = the reference: the ones select_action produced while acting (ppo_agent.py:150 acts in BatchNorm TRAIN
+    #           mode, so they are taken under the batch statistics of ONE rollout step), although learn() re-evaluates
+    #           the same samples under the statistics of shuffled cross-timestep minibatches.  Measured on the MI355X
+    #           (tests/test_gpu_agent.py::test_first_minibatch_ratio_before_any_update, ResNet 2x32, 256 games x 8 plies):
+    #           the two differ by up to 1.4 nats per sample before any optimizer step, i.e. most ratios start clipped.
+    #   True  = one extra no-grad pass at the start of learn() re-computes them under learn-time statistics (running
+    #           statistics untouched): ratio == 1 / KL == 0 up to minibatch-composition noise when learning starts.
+    #   None  = automatic: True when the model has BatchNorm layers (a DELIBERATE deviation from the reference,
+    #           DESIGN.md section 2), False otherwise (nothing to reconcile).
+    recompute_old_log_probs: Optional[bool] = None
+    # True: models that expose `policy_features(x)` / `policy_linear` (ResTowerActorCritic, TinyActorCritic) act and learn
+    # through the FUSED policy head (ops.policy_head_*): the last nn.Linear of the policy head runs inside the sampler /
+    # loss kernels and the [B,13527] logits and their gradient are never materialised.  False: logits through the
+    # framework's GEMM, then ops.masked_sample / ops.ppo_loss.
+    fused_policy_head: bool = True
     mixed_precision: bool = False          # bf16 autocast of the tower (the reference uses fp16 + GradScaler)
     channels_last: bool = False
     seed: int = 42
@@ -74,6 +84,8 @@ class VecPPOAgent:
             self.optimizer = torch.optim.Adam(params, fused=True, **kw)
         except (RuntimeError, TypeError, ValueError):
             self.optimizer = torch.optim.Adam(params, **kw)
+        self.fused_head = bool(self.config.fused_policy_head and hasattr(self.model, "policy_features")
+                               and hasattr(self.model, "policy_linear"))
         self._rng = np.random.default_rng(self.config.seed)       # minibatch shuffling (ppo_agent.py:100, 298)
         self._sample_step = 0
         self._step_tensor = None        # device-side twin of _sample_step while a captured rollout graph is in use
@@ -90,26 +102,41 @@ class VecPPOAgent:
             logits, value = self.model(obs)
         return logits, value.float().reshape(-1)
 
+    def _features(self, obs):
+        """(policy features [B,K] float32, value [B]) for the fused policy head"""
+        if obs.dtype != torch.float32 and not self.config.mixed_precision:
+            obs = obs.float()
+        if self.config.channels_last:
+            obs = obs.contiguous(memory_format=torch.channels_last)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=self.config.mixed_precision):
+            feat, value = self.model.policy_features(obs)
+        return feat.float(), value.float().reshape(-1)
+
     @torch.no_grad()
     def select_actions(self, obs, legal_mask, *, is_training=True):
         """obs [N,46,9,9], legal_mask bool [N,13527] (or the same sets bit-packed, int32 [N,424]) ->
         (action int64 [N], log_prob [N], value [N])."""
         self.model.train(is_training)                              # BatchNorm uses batch statistics while acting
-        logits, value = self._forward(obs)
-        if self._step_tensor is not None:                          # graph-captured rollout: counter lives on the device
-            action, logp = ops.masked_sample(logits, legal_mask, self.config.seed, self._step_tensor,
-                                             deterministic=not is_training)
+        # graph-captured rollout: the Philox step counter lives on the device and the graph increments it
+        step = self._step_tensor if self._step_tensor is not None else self._sample_step
+        if self.fused_head:
+            feat, value = self._features(obs)
+            lin = self.model.policy_linear
+            action, logp = ops.policy_head_sample(feat, lin.weight, lin.bias, legal_mask, self.config.seed, step,
+                                                  deterministic=not is_training)
+        else:
+            logits, value = self._forward(obs)
+            action, logp = ops.masked_sample(logits, legal_mask, self.config.seed, step, deterministic=not is_training)
+        if self._step_tensor is not None:
             self._step_tensor.add_(1)
-            return action, logp, value
-        action, logp = ops.masked_sample(logits, legal_mask, self.config.seed, self._sample_step,
-                                         deterministic=not is_training)
-        self._sample_step += 1
+        else:
+            self._sample_step += 1
         return action, logp, value
 
     @torch.no_grad()
     def get_values(self, obs):
         self.model.eval()
-        _, value = self._forward(obs)
+        _, value = self._features(obs) if self.fused_head else self._forward(obs)   # no logits GEMM for a value
         return value
 
     def select_action(self, obs, legal_mask, *, is_training=True):
@@ -126,7 +153,7 @@ class VecPPOAgent:
 
     # ------------------------------------------------------------------ learning
     @torch.no_grad()
-    def _recompute_log_probs(self, obs, masks, actions):
+    def _recompute_log_probs(self, obs, masks, actions, dense=True):
         """log-probs of the stored actions under the CURRENT weights and learn-time (train-mode, minibatch) BatchNorm
         statistics; running statistics and num_batches_tracked are left exactly as they were."""
         bns = [m for m in self.model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
@@ -138,8 +165,13 @@ class VecPPOAgent:
             for start in range(0, obs.shape[0], self.config.minibatch_size):
                 sl = slice(start, start + self.config.minibatch_size)
                 idx = torch.arange(sl.start, min(sl.stop, obs.shape[0]), device=self.device)
-                logits, _ = self._forward(_gather_obs(obs, idx))
-                out[sl], _ = ops.evaluate_actions(logits, masks[sl], actions[sl])
+                if self.fused_head:
+                    feat, _ = self._features(_gather_obs(obs, idx))
+                    lin = self.model.policy_linear
+                    out[sl], _ = ops.policy_head_evaluate(feat, lin.weight, lin.bias, masks[sl], actions[sl], dense)
+                else:
+                    logits, _ = self._forward(_gather_obs(obs, idx))
+                    out[sl], _ = ops.evaluate_actions(logits, masks[sl], actions[sl])
         finally:
             for m, (mom, nbt) in zip(bns, saved):
                 m.momentum = mom
@@ -162,8 +194,15 @@ class VecPPOAgent:
             n, mean, std = global_advantage_moments(adv, self.group)
             ok = (std > 1e-8) & (n > 1)                            # ppo_agent.py:277-282, decided on the device
             adv = torch.where(ok, ((adv.double() - mean) / torch.where(ok, std, torch.ones_like(std))).float(), adv)
-        if cfg.recompute_old_log_probs:
-            old_logp = self._recompute_log_probs(obs, masks, actions)
+        recompute = cfg.recompute_old_log_probs
+        if recompute is None:
+            recompute = any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in self.model.modules())
+        # masks written by the env kernel never have more than 593 legal actions: the fused head can skip its dense path
+        dense = not bool(batch.get("masks_from_env", False))
+        if self.fused_head and not ops.is_packed(masks):
+            masks = ops.pack_mask_bits(masks)                      # user-provided bool masks: packed once per learn()
+        if recompute:
+            old_logp = self._recompute_log_probs(obs, masks, actions, dense)
         num = obs.shape[0]
         check_equal_batches(num, self.device, self.group)          # same minibatch count (= collectives) on every rank
         indices = np.arange(num)
@@ -175,14 +214,30 @@ class VecPPOAgent:
             perm = torch.from_numpy(indices.copy()).to(self.device)   # a copy: `indices` is reshuffled in place next epoch
             for start in range(0, num, cfg.minibatch_size):
                 idx = perm[start:start + cfg.minibatch_size]
-                logits, values = self._forward(_gather_obs(obs, idx))
-                loss, stats = ops.ppo_loss(logits, values, masks.index_select(0, idx), actions.index_select(0, idx),
-                                           old_logp.index_select(0, idx), adv.index_select(0, idx),
-                                           ret.index_select(0, idx), old_values.index_select(0, idx),
-                                           cfg.clip_epsilon, cfg.value_loss_coeff, cfg.entropy_coef,
-                                           cfg.enable_value_clipping)
+                rest = (masks.index_select(0, idx), actions.index_select(0, idx), old_logp.index_select(0, idx),
+                        adv.index_select(0, idx), ret.index_select(0, idx), old_values.index_select(0, idx),
+                        cfg.clip_epsilon, cfg.value_loss_coeff, cfg.entropy_coef, cfg.enable_value_clipping)
                 self.bucket.begin()
-                loss.backward()
+                if self.fused_head:
+                    # fused policy head: the kernels return d loss / d (features, values) and write the Linear layer's
+                    # weight / bias gradients straight into the flat all-reduce buffer; the tower's backward starts
+                    # from the two small tensors (no autograd node, no scaling or copy pass over the 8.8 MB dW)
+                    feat, values = self._features(_gather_obs(obs, idx))
+                    lin = self.model.policy_linear
+                    gw = self.bucket.view_of(lin.weight)
+                    gb = self.bucket.view_of(lin.bias) if lin.bias is not None else None
+                    direct = gw.is_contiguous()
+                    stats, dfeat, dW, dbias, dvalues = ops.policy_head_loss_grads(
+                        feat.detach(), lin.weight.detach(), None if lin.bias is None else lin.bias.detach(), values.detach(),
+                        *rest, dense_rows_possible=dense, out_dweight=gw if direct else None, out_dbias=gb if direct else None)
+                    torch.autograd.backward([feat, values], [dfeat, dvalues.to(values.dtype)])
+                    lin.weight.grad = dW
+                    if lin.bias is not None:
+                        lin.bias.grad = dbias
+                else:
+                    logits, values = self._forward(_gather_obs(obs, idx))
+                    loss, stats = ops.ppo_loss(logits, values, *rest)
+                    loss.backward()
                 self.bucket.gather()
                 self.bucket.all_reduce_mean()                      # RCCL over xGMI when world_size > 1
                 flat = self.bucket.flat

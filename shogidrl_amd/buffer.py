@@ -130,6 +130,7 @@ class VecExperienceBuffer:
                "returns": f(self.returns), "dones": f(self.dones), "legal_masks": f(self.legal_masks[:T])}
         if self.legal_bits is not None:
             out["legal_bits"] = f(self.legal_bits[:T])     # what the loss kernel reads; "legal_masks" stays the contract
+        out["masks_from_env"] = True                       # written by the env kernel: never more than 593 legal actions per row
         return out
 
     def clear(self):

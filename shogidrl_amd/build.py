@@ -6,7 +6,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG, "csrc", "ksh_lib.hip")
 OUT = os.path.join(PKG, "libkeisei_hip.so")
-DEPS = [SRC] + [os.path.join(PKG, "csrc", f) for f in ("ksh_env_kernel.h", "ksh_ppo_kernels.h", "ksh_tables.h", "ksh_tower_kernels.h",
+DEPS = [SRC] + [os.path.join(PKG, "csrc", f) for f in ("ksh_env_kernel.h", "ksh_ppo_kernels.h", "ksh_head_kernels.h", "ksh_tables.h", "ksh_tower_kernels.h",
                                                             "ksh_device_util.h")] + \
        [os.path.join(os.path.dirname(PKG), "include", "keisei_hip.h")]
 

@@ -1,0 +1,744 @@
+// ksh_head_kernels.h -- the policy head of the actor-critic FUSED with the masked soft-max tail, for gfx950.
+//
+// What it replaces (reference = /root/reference/keisei/):
+//   training/models/resnet_tower.py:63-69   policy_head's nn.Linear(2*9*9, 13527)  (core/neural_network.py:17 for the tiny CNN)
+//   core/base_actor_critic.py:64-116        get_action_and_value tail: masked soft-max -> sample / arg-max -> log-prob
+//   core/base_actor_critic.py:139-184       evaluate_actions tail: log-prob, entropy
+//   core/ppo_agent.py:340-383               clipped-surrogate loss lines; and the autograd backward of all of it
+//
+// The reference materialises logits[B,13527] (hipBLASLt: 221 MB of float32 per 4096-row minibatch), masks them, and
+// autograd later reads a dense dlogits of the same size back through two more GEMMs.  A real position has ~50 legal
+// actions out of 13 527 (never more than 593), so 99.6 % of that contraction multiplies into -inf.  Here:
+//
+//   sparse rows (the production path, n_legal <= 1024): one WAVE per sample.  The packed legal bit-set becomes an id
+//       list in LDS, and only those rows of W are gathered: z_j = <feat_b, W_j> + bias_j with 8 lanes per action
+//       (16 actions in flight per wave, 16-byte loads, 3 DPP-sized reduction steps).  Soft-max statistics, sampling or the
+//       PPO loss and its gradient dz stay in LDS; dfeat_b = sum_j dz_j W_j re-gathers the same (cache-resident) rows;
+//       dz is scattered into a transposed scratch dzT[a][b] + a transposed bit matrix, from which the weight-gradient
+//       kernels build dW_a = sum_b dzT[a][b] feat_b and dbias_a in ascending b: no float atomics, bit-reproducible.
+//       Logits and dlogits never exist in HBM.
+//   dense rows (n_legal > 1024: only hand-made masks, e.g. the all-ones masks of the reference's unit tests): the
+//       contraction is genuinely dense there, so it runs on the matrix cores: an LDS-tiled float32 MFMA GEMM
+//       (v_mfma_f32_32x32x2_f32: exact float32, no xf32 on gfx950) produces the logits of the flagged rows, the
+//       block-per-row loss kernel of ksh_ppo_kernels.h does the soft-max / loss / dlogits, and two more MFMA GEMMs
+//       produce their dfeat rows and add their dW / dbias contribution.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ksh_ppo_kernels.h"
+
+#define KSH_HEAD_WPB 4      // waves (= rows) per block of the row kernels
+#define KSH_HEAD_CAP 1024   // legal ids per row the sparse path holds (Shogi's maximum is 593)
+
+struct KshHeadArgs {
+    const float *feat;          // [B][K] policy features (input of the Linear layer)
+    const float *W;             // [A][K] nn.Linear.weight
+    const float *bias;          // [A] or null
+    int K;                      // even, <= KMAX of the instantiation
+    const uint32_t *mask_bits;  // [B][424] packed legal masks
+    int B;
+    // ---- sampling (ksh_head_sample_kernel)
+    unsigned long long seed, step;
+    const unsigned long long *step_dev;
+    int deterministic;
+    long long *action;
+    float *log_prob;
+    // ---- loss (ksh_head_loss_kernel); `L` carries the per-row inputs, partial sums and optional per-row outputs
+    KshLossArgs L;
+    int want_grad;              // 0: evaluate only (log-prob / entropy / loss terms), nothing below is touched
+    float *dfeat;               // [B][K]
+    float *dzT;                 // [A][B] scratch: d loss / d logit, transposed, only legal entries are ever written
+    uint32_t *bitsT;            // [A][BW] transposed legal bit matrix (BW = ceil(B/32)), zeroed by the caller
+    int BW;
+    unsigned *n_over;           // counter of rows left to the dense path
+};
+
+__device__ __forceinline__ void ksh_head_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Legal ids of one packed row -> list[] in ASCENDING order, without atomics: lane l owns dwords 7l .. 7l+6 of the row,
+// an inclusive scan of the per-lane popcounts gives every lane its output offset.  Returns the number of legal ids;
+// ids beyond `cap` are not stored.
+__device__ __forceinline__ int ksh_head_collect(const uint32_t *__restrict__ brow, int lane, unsigned short *list, int cap) {
+    uint32_t wd[7];
+    int c = 0;
+#pragma unroll
+    for (int it = 0; it < 7; it++) {
+        const int i = 7 * lane + it;
+        uint32_t v = i < KSH_PBITROW ? brow[i] : 0u;
+        if (i == 422) v &= 0x007FFFFFu;   // bits >= 13527 never count
+        if (i >= 423) v = 0u;
+        wd[it] = v;
+        c += __popc(v);
+    }
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl(incl, lane >= o ? lane - o : 0);
+        if (lane >= o) incl += t;
+    }
+    const int n = __shfl(incl, 63);
+    int pos = incl - c;
+#pragma unroll
+    for (int it = 0; it < 7; it++) {
+        uint32_t v = wd[it];
+        const int j0 = 32 * (7 * lane + it);
+        while (v) {
+            const int bit = __ffs((int)v) - 1;
+            v &= v - 1u;
+            if (pos < cap) list[pos] = (unsigned short)(j0 + bit);
+            pos++;
+        }
+    }
+    ksh_head_wave_sync();
+    return n;
+}
+
+// Rows of W and of feat start 8-byte aligned (K is even, not a multiple of 4 in general: 162): a row is read as
+// "quads" of 16 bytes -- gfx9 global loads only need dword alignment -- plus one trailing pair when K % 4 == 2.
+struct __attribute__((packed, aligned(8))) ksh_f4a8 {
+    float x, y, z, w;
+};
+__device__ __forceinline__ float4 ksh_ld_quad(const float *row, int q, int nq, bool tail) {
+    if (q < nq) {
+        const ksh_f4a8 v = reinterpret_cast<const ksh_f4a8 *>(row)[q];
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    if (q == nq && tail) {
+        const float2 v = reinterpret_cast<const float2 *>(row)[2 * q];
+        return make_float4(v.x, v.y, 0.0f, 0.0f);
+    }
+    return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// z_e = <feat, W[list[e]]> + bias for the first n list entries.  8 lanes per action: lane s of a sub-group owns the
+// quads q = s, s+8, ... of a row (8 lanes x 16 B = one 128-byte line per load instruction and sub-group); every
+// sub-group works on TWO actions at once (e and e+8), CH quads each, so 2*CH independent 16-byte loads are in flight
+// per lane before the first multiply.  feat: this wave's feature row in LDS (16-byte aligned, zero-padded to KMAX).
+template <int KMAX>
+__device__ __forceinline__ void ksh_head_logits(const KshHeadArgs &a, const float *feat, const unsigned short *list, int n,
+                                                int lane, float *z) {
+    constexpr int CH = (KMAX / 4 + 7) / 8 < 6 ? (KMAX / 4 + 7) / 8 : 6;   // quads per lane and chunk
+    const int s = lane & 7, g = lane >> 3;
+    const int nq = a.K >> 2;
+    const bool tail = (a.K & 2) != 0;
+    const int nqt = nq + (tail ? 1 : 0);
+    const float4 *f4 = reinterpret_cast<const float4 *>(feat);
+    for (int e0 = 0; e0 < n; e0 += 16) {           // wave-uniform trip count
+        const int eA = e0 + g, eB = e0 + 8 + g;
+        const int jA = (int)list[eA < n ? eA : 0], jB = (int)list[eB < n ? eB : 0];
+        const float *rA = a.W + (size_t)jA * (size_t)a.K, *rB = a.W + (size_t)jB * (size_t)a.K;
+        float accA = 0.0f, accB = 0.0f;
+        for (int c0 = 0; c0 < nqt; c0 += 8 * CH) {  // one round for K = 162
+            float4 wA[CH], wB[CH];
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                wA[c] = ksh_ld_quad(rA, c0 + s + 8 * c, nq, tail);
+                wB[c] = ksh_ld_quad(rB, c0 + s + 8 * c, nq, tail);
+            }
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                const int q = c0 + s + 8 * c;
+                const float4 f = q < nqt ? f4[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                accA = fmaf(wA[c].x, f.x, accA); accA = fmaf(wA[c].y, f.y, accA);
+                accA = fmaf(wA[c].z, f.z, accA); accA = fmaf(wA[c].w, f.w, accA);
+                accB = fmaf(wB[c].x, f.x, accB); accB = fmaf(wB[c].y, f.y, accB);
+                accB = fmaf(wB[c].z, f.z, accB); accB = fmaf(wB[c].w, f.w, accB);
+            }
+        }
+#pragma unroll
+        for (int o = 1; o <= 4; o <<= 1) {
+            accA += __shfl_xor(accA, o);
+            accB += __shfl_xor(accB, o);
+        }
+        if (s == 0 && eA < n) z[eA] = accA + (a.bias != nullptr ? a.bias[jA] : 0.0f);
+        if (s == 0 && eB < n) z[eB] = accB + (a.bias != nullptr ? a.bias[jB] : 0.0f);
+    }
+    ksh_head_wave_sync();
+}
+
+// one lane's own dot product (ids beyond the list capacity in the sampler: hand-made dense masks only)
+__device__ __forceinline__ float ksh_head_logit_serial(const KshHeadArgs &a, const float *feat, int j) {
+    const float *wrow = a.W + (size_t)j * (size_t)a.K;
+    float acc = 0.0f;
+    for (int k = 0; k < a.K; k++) acc = fmaf(wrow[k], feat[k], acc);
+    return acc + (a.bias != nullptr ? a.bias[j] : 0.0f);
+}
+
+template <int KMAX>
+struct KshHeadLds {
+    unsigned short list[KSH_HEAD_WPB][KSH_HEAD_CAP];
+    float z[KSH_HEAD_WPB][KSH_HEAD_CAP];
+    __attribute__((aligned(16))) float feat[KSH_HEAD_WPB][KMAX];
+};
+
+template <int KMAX>
+__device__ __forceinline__ void ksh_head_stage_feat(const KshHeadArgs &a, int b, int lane, float *dst) {
+    const float2 *src = reinterpret_cast<const float2 *>(a.feat + (size_t)b * (size_t)a.K);
+    float2 *d2 = reinterpret_cast<float2 *>(dst);
+    const int np = a.K >> 1;
+    for (int p = lane; p < ((np + 1) & ~1); p += 64) d2[p] = p < np ? src[p] : make_float2(0.0f, 0.0f);   // padded to a quad
+    ksh_head_wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------ fused head + sampler
+// get_action_and_value's tail without logits in memory: gather-dot of the legal rows of W, Gumbel-max sample (or
+// arg-max), Categorical log-prob.  Same arithmetic after the logits as ksh_masked_sample_kernel.
+template <int KMAX>
+__global__ void __launch_bounds__(64 * KSH_HEAD_WPB) ksh_head_sample_kernel(KshHeadArgs a) {
+    __shared__ KshHeadLds<KMAX> S;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x * KSH_HEAD_WPB + wv;
+    if (b >= a.B) return;  // wave-uniform
+    unsigned long long step = a.step;
+    if (a.step_dev != nullptr) step += a.step_dev[0];
+    const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32), s0 = (uint32_t)step, s1 = (uint32_t)(step >> 32);
+    const bool det = a.deterministic != 0;
+    const uint32_t *brow = a.mask_bits + (size_t)b * KSH_PBITROW;
+    const int total = ksh_head_collect(brow, lane, S.list[wv], KSH_HEAD_CAP);
+    const int n = total < KSH_HEAD_CAP ? total : KSH_HEAD_CAP;
+    ksh_head_stage_feat<KMAX>(a, b, lane, S.feat[wv]);
+    ksh_head_logits<KMAX>(a, S.feat[wv], S.list[wv], n, lane, S.z[wv]);
+    KshSampleAcc A = {-INFINITY, 0.0f, -INFINITY, 0.0f, -1};
+    auto visit = [&](int j, float z) {
+        ksh_ms_merge(A.m, A.s, z, 1.0f);
+        float k = z;
+        if (!det) k = z - logf(-logf(ksh_uniform_open(ksh_philox((uint32_t)j, (uint32_t)b, s0, s1, k0, k1))));
+        if (A.idx < 0 || k > A.key || (k == A.key && j < A.idx)) { A.key = k; A.idx = j; A.zbest = z; }
+    };
+    for (int e = lane; e < n; e += 64) visit((int)S.list[wv][e], S.z[wv][e]);
+    if (total > KSH_HEAD_CAP) {
+        // dense hand-made mask: the ids that did not fit are the ones after the first CAP set bits; every lane re-walks
+        // its own dwords and computes those logits by itself (correct for any density; production rows never get here)
+        int seen = 0;
+        {   // number of set bits in the dwords of lower lanes = this lane's starting rank
+            int c = 0;
+            for (int it = 0; it < 7; it++) {
+                const int i = 7 * lane + it;
+                uint32_t v = i < KSH_PBITROW ? brow[i] : 0u;
+                if (i == 422) v &= 0x007FFFFFu;
+                if (i >= 423) v = 0u;
+                c += __popc(v);
+            }
+            int incl = c;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl(incl, lane >= o ? lane - o : 0);
+                if (lane >= o) incl += t;
+            }
+            seen = incl - c;
+        }
+        for (int it = 0; it < 7; it++) {
+            const int i = 7 * lane + it;
+            uint32_t v = i < KSH_PBITROW ? brow[i] : 0u;
+            if (i == 422) v &= 0x007FFFFFu;
+            if (i >= 423) v = 0u;
+            while (v) {
+                const int bit = __ffs((int)v) - 1;
+                v &= v - 1u;
+                if (seen >= KSH_HEAD_CAP) visit(32 * i + bit, ksh_head_logit_serial(a, S.feat[wv], 32 * i + bit));
+                seen++;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float m2 = __shfl_xor(A.m, o), s2 = __shfl_xor(A.s, o);
+        ksh_ms_merge(A.m, A.s, m2, s2);
+        const float k2 = __shfl_xor(A.key, o), z2 = __shfl_xor(A.zbest, o);
+        const int i2 = __shfl_xor(A.idx, o);
+        if (i2 >= 0 && (A.idx < 0 || k2 > A.key || (k2 == A.key && i2 < A.idx))) { A.key = k2; A.idx = i2; A.zbest = z2; }
+    }
+    if (lane == 0) {
+        long long act;
+        float lp;
+        if (A.idx < 0) {   // no legal action: uniform over ALL actions (base_actor_critic.py:93-101)
+            const uint32_t x = ksh_philox(0xFFFFFFFFu, (uint32_t)b, s0, s1, k0, k1);
+            act = det ? 0 : (long long)(((unsigned long long)x * (unsigned long long)KSH_PA) >> 32);
+            lp = logf(1.0f / (float)KSH_PA);
+        } else {
+            act = A.idx;
+            float p = expf(A.zbest - A.m) / A.s;
+            p = fminf(fmaxf(p, KSH_EPS), 1.0f - KSH_EPS);
+            lp = logf(p);
+        }
+        a.action[b] = act;
+        a.log_prob[b] = lp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ fused head + PPO loss
+// One wave per sample: logits of the legal actions (never stored), evaluate_actions' log-prob / entropy, the loss terms
+// (-> L.partial), and -- when want_grad -- dfeat[b] and the transposed sparse dz for the weight-gradient kernel.
+template <int KMAX>
+__global__ void __launch_bounds__(64 * KSH_HEAD_WPB) ksh_head_loss_kernel(KshHeadArgs a) {
+    __shared__ KshHeadLds<KMAX> S;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x * KSH_HEAD_WPB + wv;
+    if (b >= a.B) return;  // wave-uniform
+    const KshLossArgs &L = a.L;
+    float *part = L.partial + (size_t)b * 8;
+    const int n = ksh_head_collect(a.mask_bits + (size_t)b * KSH_PBITROW, lane, S.list[wv], KSH_HEAD_CAP);
+    if (n > KSH_HEAD_CAP) {            // wave-uniform: a dense row, left to the MFMA path
+        if (lane == 0) { part[6] = 1.0f; atomicAdd(a.n_over, 1u); }
+        return;
+    }
+    unsigned short *list = S.list[wv];
+    float *z = S.z[wv];
+    ksh_head_stage_feat<KMAX>(a, b, lane, S.feat[wv]);
+    ksh_head_logits<KMAX>(a, S.feat[wv], list, n, lane, z);
+    // pass 1: soft-max statistics
+    float m = -INFINITY, s = 0.0f;
+    for (int e = lane; e < n; e += 64) ksh_ms_merge(m, s, z[e], 1.0f);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float m2 = __shfl_xor(m, o), s2 = __shfl_xor(s, o);
+        ksh_ms_merge(m, s, m2, s2);
+    }
+    const bool none = n == 0;
+    const float inv_s = none ? 0.0f : 1.0f / s;
+    const int act = (int)L.actions[b];
+    const float invB = 1.0f / (float)L.B;
+    // pass 2: entropy terms and the taken action's probability
+    float e1 = 0.0f, e2 = 0.0f, ya = 0.0f;
+    for (int e = lane; e < n; e += 64) {
+        const float y = expf(z[e] - m) * inv_s;
+        const bool u = (y >= KSH_EPS) && (y <= 1.0f - KSH_EPS);
+        const float l = logf(fminf(fmaxf(y, KSH_EPS), 1.0f - KSH_EPS));
+        e1 += y * l;
+        e2 += u ? y : 0.0f;
+        if ((int)list[e] == act) ya = y;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        e1 += __shfl_xor(e1, o);
+        e2 += __shfl_xor(e2, o);
+        ya += __shfl_xor(ya, o);
+    }
+    float new_logp, H;
+    bool ua;
+    if (none) {   // all-illegal row -> uniform over all actions, detached (base_actor_critic.py:168-174)
+        new_logp = logf(1.0f / (float)KSH_PA);
+        H = -new_logp;
+        ua = false;
+        ya = 1.0f;
+    } else {
+        ua = (ya >= KSH_EPS) && (ya <= 1.0f - KSH_EPS);
+        new_logp = logf(fminf(fmaxf(ya, KSH_EPS), 1.0f - KSH_EPS));
+        H = -e1;
+    }
+    const float old_lp = L.old_logp[b], Adv = L.adv[b];
+    const float ratio = expf(new_logp - old_lp);
+    const float surr1 = ratio * Adv;
+    const float surr2 = fminf(fmaxf(ratio, 1.0f - L.clip_eps), 1.0f + L.clip_eps) * Adv;
+    const float gr = (surr1 <= surr2) ? Adv : 0.0f;
+    const float pol = (ua && !none) ? (-gr * ratio * invB) : 0.0f;
+    const float ce = L.ent_coef * invB;
+    const float c = ce * (e1 + e2) + pol;
+    if (lane == 0) {
+        const float V = L.values[b], Rt = L.ret[b];
+        part[0] = fminf(surr1, surr2);
+        part[1] = (V - Rt) * (V - Rt);
+        float vc = 0.0f;
+        if (L.value_clip) {
+            const float ov = L.old_values[b];
+            const float Vc = ov + fminf(fmaxf(V - ov, -L.clip_eps), L.clip_eps);
+            vc = (Vc - Rt) * (Vc - Rt);
+        }
+        part[2] = vc;
+        part[3] = H;
+        part[4] = old_lp - new_logp;
+        part[5] = (fabsf(ratio - 1.0f) > L.clip_eps) ? 1.0f : 0.0f;
+        part[6] = 0.0f;
+        part[7] = 0.0f;
+        if (L.row_logp != nullptr) L.row_logp[b] = new_logp;
+        if (L.row_entropy != nullptr) L.row_entropy[b] = H;
+    }
+    if (!a.want_grad) return;   // wave-uniform
+    // pass 3: dz_e = y_e (G_e - c) in place of the logits
+    for (int e = lane; e < n; e += 64) {
+        const float y = expf(z[e] - m) * inv_s;
+        const bool u = (y >= KSH_EPS) && (y <= 1.0f - KSH_EPS);
+        const float l = logf(fminf(fmaxf(y, KSH_EPS), 1.0f - KSH_EPS));
+        float G = ce * (l + (u ? 1.0f : 0.0f));
+        if ((int)list[e] == act) G += pol / y;
+        z[e] = y * (G - c);
+    }
+    ksh_head_wave_sync();
+#ifndef KSH_DIAG_NO_DFEAT
+    // dfeat[b] = sum_e dz_e W[list[e]]: lanes own the quads q = lane + 64 i of the row (one 16-byte load per entry and
+    // lane for K = 162), U entries' loads in flight at once
+    {
+        constexpr int QQ = (KMAX / 4 + 63) / 64;
+        constexpr int U = QQ == 1 ? 8 : 2;
+        const int nq = a.K >> 2;
+        const bool tail = (a.K & 2) != 0;
+        float4 acc[QQ];
+#pragma unroll
+        for (int i = 0; i < QQ; i++) acc[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int e0 = 0; e0 < n; e0 += U) {
+            float4 w[U][QQ];
+            float dz[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int e = e0 + u;
+                dz[u] = e < n ? z[e] : 0.0f;
+                const float *wrow = a.W + (size_t)list[e < n ? e : 0] * (size_t)a.K;
+#pragma unroll
+                for (int i = 0; i < QQ; i++) w[u][i] = ksh_ld_quad(wrow, lane + 64 * i, nq, tail);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+#pragma unroll
+                for (int i = 0; i < QQ; i++) {
+                    acc[i].x = fmaf(dz[u], w[u][i].x, acc[i].x); acc[i].y = fmaf(dz[u], w[u][i].y, acc[i].y);
+                    acc[i].z = fmaf(dz[u], w[u][i].z, acc[i].z); acc[i].w = fmaf(dz[u], w[u][i].w, acc[i].w);
+                }
+            }
+        }
+        float2 *drow = reinterpret_cast<float2 *>(a.dfeat + (size_t)b * (size_t)a.K);
+#pragma unroll
+        for (int i = 0; i < QQ; i++) {
+            const int q = lane + 64 * i;
+            if (q < nq || (q == nq && tail)) drow[2 * q] = make_float2(acc[i].x, acc[i].y);
+            if (q < nq) drow[2 * q + 1] = make_float2(acc[i].z, acc[i].w);
+        }
+    }
+#endif
+    // transposed scatter for the weight gradient: dzT[a][b], bit b of bitsT row a
+#ifndef KSH_DIAG_NO_SCATTER
+    for (int e = lane; e < n; e += 64) {
+        const int j = (int)list[e];
+        a.dzT[(size_t)j * (size_t)a.B + (size_t)b] = z[e];
+#ifndef KSH_DIAG_NO_ATOMIC
+        atomicOr(&a.bitsT[(size_t)j * (size_t)a.BW + (size_t)(b >> 5)], 1u << (b & 31));
+#endif
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------ weight gradient
+// dW[a][:] = sum over the samples b in which action a was legal (ascending b) of dzT[a][b] * feat[b][:], dbias[a] = the
+// sum of those dzT -- from the transposed bit matrix, without float atomics, in three small kernels so that neither the
+// ~10 000 actions that were legal nowhere nor the few that were legal almost everywhere set the pace:
+//   scan     one wave per action counts its legal samples.  Light actions (<= light_max samples: almost all of them)
+//            become ONE work item covering the whole bit row; heavy ones (a move that is legal in most positions) are
+//            split into their non-empty sample segments (at most 16).  Items are appended to a work list (one integer
+//            atomic per block picks the slots: the ORDER of the list is arbitrary, the CONTENT of every item is not);
+//            table[a] remembers where a heavy action's items start.
+//   work     a fixed-size grid of waves walks the list; an item's samples are visited in ascending order, T feature
+//            rows in flight.  A light item writes dW[a] / dbias[a] directly, a segment its partial row to scratch.
+//   combine  one wave per action: heavy actions add their partial rows in segment order; actions that were legal
+//            nowhere get their zero row here -- which IS the zero-fill of the gradient; light ones are already done.
+// Every sum has a fixed order, so the result is bit-reproducible and independent of scheduling.
+struct KshHeadDwArgs {
+    const float *feat;       // [B][K]
+    const float *dzT;        // [A][B]
+    const uint32_t *bitsT;   // [A][BW]
+    float *dW;               // [A][K]
+    float *dbias;            // [A] or null
+    int B, BW, K, A;
+    int SEGW, NSEG;          // dwords per segment, segments per bit row (<= 16)
+    int light_max;           // actions with at most this many legal samples are one work item
+    unsigned *n_items;       // work-list length (zeroed by the caller)
+    uint32_t *items;         // [A * NSEG]  action * 32 + segment (segment 31 = the whole row, result written directly)
+    int *table;              // [A][2]  first item, segment mask (0 = legal nowhere, bit 31 = light: done by the work kernel)
+    float *partial;          // [A * NSEG][K] partial rows
+    float *partial_dz;       // [A * NSEG]
+};
+
+#define KSH_DW_WPB 4
+#define KSH_DW_SCAN_WPB 16
+#define KSH_DW_ALL 31u
+
+extern "C" __global__ void __launch_bounds__(64 * KSH_DW_SCAN_WPB) ksh_head_dw_scan_kernel(KshHeadDwArgs a) {
+    __shared__ int s_cnt[KSH_DW_SCAN_WPB];
+    __shared__ int s_base;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = blockIdx.x * KSH_DW_SCAN_WPB + wv;
+    uint32_t m = 0;
+    int total = 0;
+    if (j < a.A) {   // wave-uniform
+        const uint32_t *brow = a.bitsT + (size_t)j * (size_t)a.BW;
+        for (int d = lane; d < a.BW; d += 64) {
+            const uint32_t w = brow[d];
+            if (w != 0u) { m |= 1u << (d / a.SEGW); total += __popc(w); }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            m |= (uint32_t)__shfl_xor((int)m, o);
+            total += __shfl_xor(total, o);
+        }
+    }
+    const bool light = total > 0 && total <= a.light_max;
+    const int mine = total == 0 ? 0 : (light ? 1 : __popc(m));
+    if (lane == 0) s_cnt[wv] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int sum = 0;
+        for (int w = 0; w < KSH_DW_SCAN_WPB; w++) sum += s_cnt[w];
+        s_base = sum ? (int)atomicAdd(a.n_items, (unsigned)sum) : 0;
+    }
+    __syncthreads();
+    if (j >= a.A) return;
+    int base = s_base;
+    for (int w = 0; w < wv; w++) base += s_cnt[w];
+    if (light) {
+        if (lane == 0) a.items[base] = (uint32_t)j * 32u + KSH_DW_ALL;
+    } else if (lane < 16 && ((m >> lane) & 1u)) {
+        a.items[base + __popc(m & ((1u << lane) - 1u))] = (uint32_t)j * 32u + (uint32_t)lane;
+    }
+    if (lane == 0) { a.table[2 * j] = base; a.table[2 * j + 1] = light ? (int)0x80000000u : (int)m; }
+}
+
+#define KSH_DW_WIN 256   // samples per LDS window of the work kernel
+
+template <int KMAX>
+__global__ void __launch_bounds__(64 * KSH_DW_WPB) ksh_head_dw_work_kernel(KshHeadDwArgs a) {
+    constexpr int QQ = (KMAX / 4 + 63) / 64;
+    constexpr int T = QQ == 1 ? 8 : 2;
+    __shared__ int s_rows[KSH_DW_WPB][KSH_DW_WIN];
+    __shared__ float s_dz[KSH_DW_WPB][KSH_DW_WIN];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wave = blockIdx.x * KSH_DW_WPB + wv;
+    const int nwaves = (int)gridDim.x * KSH_DW_WPB;
+    const int n_items = (int)*a.n_items;
+    const int nq = a.K >> 2;
+    const bool tail = (a.K & 2) != 0;
+    int *rows = s_rows[wv];
+    float *dzl = s_dz[wv];
+    for (int it = wave; it < n_items; it += nwaves) {     // wave-uniform
+        const uint32_t item = a.items[it];
+        const int j = (int)(item >> 5), sg = (int)(item & 31u);
+        const bool whole = sg == (int)KSH_DW_ALL;
+        const int d0 = whole ? 0 : sg * a.SEGW, d1 = whole ? a.BW : ((d0 + a.SEGW < a.BW) ? d0 + a.SEGW : a.BW);
+        const uint32_t *brow = a.bitsT + (size_t)j * (size_t)a.BW;
+        const float *zrow = a.dzT + (size_t)j * (size_t)a.B;
+        float4 acc[QQ];
+#pragma unroll
+        for (int i = 0; i < QQ; i++) acc[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float dzsum = 0.0f;
+        for (int c0 = d0; c0 < d1; c0 += 64) {
+            // lane = dword of the bit row; an inclusive scan of the popcounts ranks every legal sample of the chunk
+            const int d = c0 + lane;
+            const uint32_t word = d < d1 ? brow[d] : 0u;
+            const int c = __popc(word);
+            int incl = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl(incl, lane >= o ? lane - o : 0);
+                if (lane >= o) incl += t;
+            }
+            const int total = __shfl(incl, 63);
+            for (int w0 = 0; w0 < total; w0 += KSH_DW_WIN) {     // windows of 256 samples (one, as a rule), ascending
+                {
+                    int pos = incl - c;
+                    uint32_t v = word;
+                    while (v) {
+                        const int bit = __ffs((int)v) - 1;
+                        v &= v - 1u;
+                        if (pos >= w0 && pos < w0 + KSH_DW_WIN) rows[pos - w0] = 32 * d + bit;
+                        pos++;
+                    }
+                }
+                ksh_head_wave_sync();
+                const int cw = total - w0 < KSH_DW_WIN ? total - w0 : KSH_DW_WIN;
+                for (int i = lane; i < cw; i += 64) dzl[i] = zrow[rows[i]];   // all of the window's dz loads in flight at once
+                ksh_head_wave_sync();
+                for (int e0 = 0; e0 < cw; e0 += T) {              // feature rows: T in flight, added in ascending order
+                    float4 f[T][QQ];
+                    float dz[T];
+#pragma unroll
+                    for (int t = 0; t < T; t++) {
+                        const bool on = e0 + t < cw;
+                        dz[t] = on ? dzl[e0 + t] : 0.0f;
+                        const float *frow = a.feat + (size_t)(on ? rows[e0 + t] : 0) * (size_t)a.K;
+#pragma unroll
+                        for (int i = 0; i < QQ; i++)
+                            f[t][i] = on ? ksh_ld_quad(frow, lane + 64 * i, nq, tail) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    }
+#pragma unroll
+                    for (int t = 0; t < T; t++) {
+                        if (e0 + t < cw) {
+                            dzsum += dz[t];
+#pragma unroll
+                            for (int i = 0; i < QQ; i++) {
+                                acc[i].x = fmaf(dz[t], f[t][i].x, acc[i].x); acc[i].y = fmaf(dz[t], f[t][i].y, acc[i].y);
+                                acc[i].z = fmaf(dz[t], f[t][i].z, acc[i].z); acc[i].w = fmaf(dz[t], f[t][i].w, acc[i].w);
+                            }
+                        }
+                    }
+                }
+                ksh_head_wave_sync();
+            }
+        }
+        // a light action is complete: straight into the gradient; a segment of a heavy one: partial row for the combine kernel
+        float2 *prow = reinterpret_cast<float2 *>(whole ? a.dW + (size_t)j * (size_t)a.K : a.partial + (size_t)it * (size_t)a.K);
+#pragma unroll
+        for (int i = 0; i < QQ; i++) {
+            const int q = lane + 64 * i;
+            if (q < nq || (q == nq && tail)) prow[2 * q] = make_float2(acc[i].x, acc[i].y);
+            if (q < nq) prow[2 * q + 1] = make_float2(acc[i].z, acc[i].w);
+        }
+        if (lane == 0) {
+            if (!whole) a.partial_dz[it] = dzsum;
+            else if (a.dbias != nullptr) a.dbias[j] = dzsum;
+        }
+    }
+}
+
+template <int KMAX>
+__global__ void __launch_bounds__(64 * KSH_DW_WPB) ksh_head_dw_combine_kernel(KshHeadDwArgs a) {
+    constexpr int QQ = (KMAX / 4 + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * KSH_DW_WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (j >= a.A) return;  // wave-uniform
+    const int nq = a.K >> 2;
+    const bool tail = (a.K & 2) != 0;
+    const int base = a.table[2 * j];
+    const unsigned tm = (unsigned)a.table[2 * j + 1];
+    if (tm & 0x80000000u) return;                           // light action: the work kernel wrote its row (wave-uniform)
+    const int cnt = __popc(tm);
+    float4 acc[QQ];
+#pragma unroll
+    for (int i = 0; i < QQ; i++) acc[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float dzsum = 0.0f;
+    for (int r = 0; r < cnt; r++) {                         // ascending segment order (the scan wrote them by rank)
+        const float *prow = a.partial + (size_t)(base + r) * (size_t)a.K;
+#pragma unroll
+        for (int i = 0; i < QQ; i++) {
+            const float4 v = ksh_ld_quad(prow, lane + 64 * i, nq, tail);
+            acc[i].x += v.x; acc[i].y += v.y; acc[i].z += v.z; acc[i].w += v.w;
+        }
+        dzsum += a.partial_dz[base + r];
+    }
+    float2 *drow = reinterpret_cast<float2 *>(a.dW + (size_t)j * (size_t)a.K);
+#pragma unroll
+    for (int i = 0; i < QQ; i++) {
+        const int q = lane + 64 * i;
+        if (q < nq || (q == nq && tail)) drow[2 * q] = make_float2(acc[i].x, acc[i].y);
+        if (q < nq) drow[2 * q + 1] = make_float2(acc[i].z, acc[i].w);
+    }
+    if (lane == 0 && a.dbias != nullptr) a.dbias[j] = dzsum;
+}
+
+// ------------------------------------------------------------------------------------------ byte mask -> packed bits
+// PolicyOutputMapper.get_legal_mask's bool[13527] rows (utils/utils.py:310-336) as the 424-dword rows the head kernels read.
+extern "C" __global__ void __launch_bounds__(KSH_ROW_THREADS) ksh_pack_mask_kernel(const uint8_t *__restrict__ mask, int B,
+                                                                                   uint32_t *__restrict__ bits) {
+    __shared__ KshRowLds R;
+    const int b = blockIdx.x;
+    ksh_build_bits(R, mask + (size_t)b * KSH_PA, (int)threadIdx.x);
+    for (int i = (int)threadIdx.x; i < KSH_PBITROW; i += KSH_ROW_THREADS) {
+        uint32_t v = R.bits[i];
+        if (i == 422) v &= 0x007FFFFFu;
+        if (i == 423) v = 0u;
+        bits[(size_t)b * KSH_PBITROW + i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dense rows: MFMA GEMM
+// C[M][N] (=, +=) A[M][Kd] * B[Kd][N] on v_mfma_f32_32x32x2_f32 (float32 in, float32 accumulate: bit for bit a k-ordered
+// fmaf chain).  64x64 block tile, four waves of one 32x32 tile each, K-step 16 staged through LDS as As[k][m] / Bs[k][n]
+// (a lane reads A[m = lane & 31][k = lane >> 5] and B[k][n = lane & 31]: consecutive lanes, consecutive LDS words).
+// Operands are addressed through (row, column) strides so that the three products of the dense path share the code:
+//   mode 0  logits[r][a]  = sum_k feat[r][k] W[a][k] + bias[a]      rows gated: only tiles / rows flagged as dense
+//   mode 1  dfeat[r][k]   = sum_a dl[r][a] W[a][k]                  rows gated likewise
+//   mode 2  dW[a][k]     += sum_r dl[r][a] feat[r][k], dbias[a] += sum_r dl[r][a]   (reduction over the flagged rows only;
+//           column N-1 of the B operand is the constant 1 that produces dbias)
+// `flags[r * 8]` != 0 marks a dense row (the loss kernels' partial[b][6]); *n_over == 0 ends every block at once.
+typedef float ksh_f32x16 __attribute__((vector_size(64)));
+
+struct KshGemmArgs {
+    const float *A;
+    long long sAm, sAk;
+    const float *Bm;
+    long long sBk, sBn;
+    float *C;
+    long long sCm;
+    int M, N, Kd;
+    const float *bias;
+    const float *flags;       // partial + 6 (stride 8 floats per row)
+    const unsigned *n_over;
+    int mode;
+    float *C2;                // mode 2: dbias
+};
+
+#define KSH_GEMM_BM 64
+#define KSH_GEMM_BK 16
+
+extern "C" __global__ void __launch_bounds__(256) ksh_head_gemm_kernel(KshGemmArgs g) {
+    __shared__ float As[KSH_GEMM_BK][KSH_GEMM_BM];
+    __shared__ float Bs[KSH_GEMM_BK][KSH_GEMM_BM];
+    __shared__ int s_any;
+    if (*g.n_over == 0u) return;                           // no dense row in this minibatch (the production case)
+    const int t = (int)threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int m0 = (int)blockIdx.x * KSH_GEMM_BM, n0 = (int)blockIdx.y * KSH_GEMM_BM;
+    if (g.mode != 2) {                                     // any flagged row in this row tile?
+        if (t == 0) s_any = 0;
+        __syncthreads();
+        if (t < KSH_GEMM_BM && m0 + t < g.M && g.flags[(size_t)(m0 + t) * 8] != 0.0f) s_any = 1;
+        __syncthreads();
+        if (!s_any) return;
+    }
+    ksh_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    const bool a_kfast = g.sAk == 1, b_kfast = g.sBk == 1;
+    bool contributed = false;
+    for (int k0 = 0; k0 < g.Kd; k0 += KSH_GEMM_BK) {
+        if (g.mode == 2) {                                 // the reduction runs over sample rows: skip steps without a dense one
+            __syncthreads();
+            if (t == 0) s_any = 0;
+            __syncthreads();
+            if (t < KSH_GEMM_BK && k0 + t < g.Kd && g.flags[(size_t)(k0 + t) * 8] != 0.0f) s_any = 1;
+            __syncthreads();
+            if (!s_any) continue;                          // block-uniform
+            contributed = true;
+        } else {
+            __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int kk, i;
+            if (a_kfast) { kk = t & 15; i = (t >> 4) + 16 * q; } else { i = t & 63; kk = (t >> 6) + 4 * q; }
+            const int m = m0 + i, k = k0 + kk;
+            float v = 0.0f;
+            if (m < g.M && k < g.Kd && (g.mode != 2 || g.flags[(size_t)k * 8] != 0.0f)) v = g.A[(long long)m * g.sAm + (long long)k * g.sAk];
+            As[kk][i] = v;
+            if (b_kfast) { kk = t & 15; i = (t >> 4) + 16 * q; } else { i = t & 63; kk = (t >> 6) + 4 * q; }
+            const int n = n0 + i;
+            const int kb = k0 + kk;
+            v = 0.0f;
+            if (n < g.N && kb < g.Kd) v = (g.mode == 2 && n == g.N - 1) ? 1.0f : g.Bm[(long long)kb * g.sBk + (long long)n * g.sBn];
+            Bs[kk][i] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KSH_GEMM_BK; kk += 2) {
+            const float av = As[kk + (lane >> 5)][32 * wm + (lane & 31)];
+            const float bv = Bs[kk + (lane >> 5)][32 * wn + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+    }
+    if (g.mode == 2 && !contributed) return;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int m = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int n = n0 + 32 * wn + (lane & 31);
+        if (m >= g.M || n >= g.N) continue;
+        if (g.mode == 2) {
+            if (n == g.N - 1) { if (g.C2 != nullptr) g.C2[m] += acc[r]; }
+            else g.C[(long long)m * g.sCm + n] += acc[r];
+        } else if (g.flags[(size_t)m * 8] != 0.0f) {
+            g.C[(long long)m * g.sCm + n] = acc[r] + (g.bias != nullptr ? g.bias[n] : 0.0f);
+        }
+    }
+}

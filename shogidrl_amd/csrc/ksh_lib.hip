@@ -11,6 +11,7 @@
 #include "../../include/keisei_hip.h"
 #include "ksh_env_kernel.h"
 #include "ksh_ppo_kernels.h"
+#include "ksh_head_kernels.h"
 #include "ksh_tower_kernels.h"
 
 static thread_local std::string g_err;
@@ -349,6 +350,7 @@ static int loss_impl(const void *logits, int logits_dtype, const uint8_t *mask, 
     a.partial = reinterpret_cast<float *>(workspace);
     a.row_logp = row_logp;
     a.row_entropy = row_entropy;
+    a.overflow_is_error = 0;
     // sparse wave-per-row kernel first; rows it flags (more legal actions than its list holds) go to the dense kernel
     a.only_overflow = 1;
     const dim3 sgrid((B + KSH_LOSS_WPB - 1) / KSH_LOSS_WPB), sblock(64 * KSH_LOSS_WPB);
@@ -364,9 +366,222 @@ static int loss_impl(const void *logits, int logits_dtype, const uint8_t *mask, 
                            (const ksh_bf16 *)logits, (ksh_bf16 *)dlogits);
     }
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(ksh_ppo_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ksh_ppo_stats_kernel, dim3(1), dim3(KSH_STATS_THREADS), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return KSH_OK;
+}
+
+// ---------------------------------------------------------------------------------- fused policy head
+// workspace layout: partial [B][8] floats | 16 words (0: dense-row counter, 1: work-list length) | bitsT [A][BW] | dzT [A][B]
+//                   | items [A*NSEG] | table [A][2] | partial rows [A*NSEG][K] | partial dz [A*NSEG]
+//                   | (dense) logits scratch [B][A] | (dense) dlogits scratch [B][A]
+struct HeadWs {
+    float *partial;
+    unsigned *n_over, *n_items;
+    uint32_t *bitsT;
+    float *dzT;
+    uint32_t *items;
+    int *table;
+    float *prow, *pdz;
+    float *zbuf, *dlbuf;
+    int BW, SEGW, NSEG;
+    size_t bytes;
+};
+static size_t head_align(size_t x) { return (x + 255) & ~(size_t)255; }
+static HeadWs head_ws(void *workspace, int B, int K, int dense) {
+    HeadWs w;
+    char *p = (char *)workspace;
+    w.partial = (float *)p;
+    w.n_over = (unsigned *)(p + (size_t)B * 32);
+    w.n_items = w.n_over + 1;
+    p += head_align((size_t)B * 32 + 64);
+    w.BW = (B + 31) / 32;
+    const int maxseg = K <= 192 ? 16 : 4;                 // partial-row scratch is [A * NSEG][K]
+    w.SEGW = (w.BW + maxseg - 1) / maxseg;
+    w.NSEG = (w.BW + w.SEGW - 1) / w.SEGW;
+    w.bitsT = (uint32_t *)p;
+    p += head_align((size_t)KSH_PA * w.BW * 4);
+    w.dzT = (float *)p;
+    p += head_align((size_t)KSH_PA * B * 4);
+    w.items = (uint32_t *)p;
+    p += head_align((size_t)KSH_PA * w.NSEG * 4);
+    w.table = (int *)p;
+    p += head_align((size_t)KSH_PA * 8);
+    w.prow = (float *)p;
+    p += head_align((size_t)KSH_PA * w.NSEG * K * 4);
+    w.pdz = (float *)p;
+    p += head_align((size_t)KSH_PA * w.NSEG * 4);
+    w.zbuf = w.dlbuf = nullptr;
+    if (dense) {
+        w.zbuf = (float *)p;
+        p += head_align((size_t)KSH_PA * B * 4);
+        w.dlbuf = (float *)p;
+        p += head_align((size_t)KSH_PA * B * 4);
+    }
+    w.bytes = (size_t)(p - (char *)workspace);
+    return w;
+}
+
+uint64_t ksh_policy_head_workspace_bytes(int B, int K, int dense_rows_possible) {
+    if (B <= 0 || K <= 0) return 0;
+    return head_ws(nullptr, B, K, dense_rows_possible).bytes;
+}
+
+int ksh_pack_mask(const uint8_t *mask, int B, uint32_t *mask_bits, void *stream) {
+    if (!mask || !mask_bits || B <= 0) return fail_arg("ksh_pack_mask: bad argument");
+    if ((reinterpret_cast<size_t>(mask_bits) & 3) != 0) return fail_arg("ksh_pack_mask: mask_bits must be 4-byte aligned");
+    hipLaunchKernelGGL(ksh_pack_mask_kernel, dim3(B), dim3(KSH_ROW_THREADS), 0, (hipStream_t)stream, mask, B, mask_bits);
+    HIP_TRY(hipGetLastError());
+    return KSH_OK;
+}
+
+static int head_common_ok(const char *who, const void *feat, const void *W, int K, const void *bits, int B) {
+    if (!feat || !W || !bits || B <= 0) { g_err = std::string(who) + ": null pointer or B <= 0"; return 0; }
+    if (K <= 0 || (K & 1) != 0 || K > 1312) { g_err = std::string(who) + ": K must be even and <= 1312"; return 0; }
+    if ((reinterpret_cast<size_t>(feat) & 7) != 0 || (reinterpret_cast<size_t>(W) & 7) != 0) {
+        g_err = std::string(who) + ": feat / W must be 8-byte aligned";
+        return 0;
+    }
+    return 1;
+}
+
+int ksh_policy_head_sample(const float *feat, const float *W, const float *bias, int K, const uint32_t *mask_bits, int B,
+                           uint64_t seed, uint64_t step, const uint64_t *step_counter, int deterministic, int64_t *action,
+                           float *log_prob, void *stream) {
+    if (!head_common_ok("ksh_policy_head_sample", feat, W, K, mask_bits, B)) return KSH_E_ARG;
+    if (!action || !log_prob) return fail_arg("ksh_policy_head_sample: null output");
+    KshHeadArgs a;
+    memset(&a, 0, sizeof a);
+    a.feat = feat; a.W = W; a.bias = bias; a.K = K; a.mask_bits = mask_bits; a.B = B;
+    a.seed = seed; a.step = step; a.step_dev = reinterpret_cast<const unsigned long long *>(step_counter);
+    a.deterministic = deterministic;
+    a.action = reinterpret_cast<long long *>(action);
+    a.log_prob = log_prob;
+    const dim3 grid((B + KSH_HEAD_WPB - 1) / KSH_HEAD_WPB), block(64 * KSH_HEAD_WPB);
+    if (K <= 192) hipLaunchKernelGGL(ksh_head_sample_kernel<192>, grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(ksh_head_sample_kernel<1312>, grid, block, 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return KSH_OK;
+}
+
+// shared by ksh_policy_head_evaluate (want_grad = 0) and ksh_policy_head_loss_fwd_bwd
+static int head_loss_impl(const float *feat, const float *W, const float *bias, int K, const uint32_t *mask_bits,
+                          const int64_t *actions, const float *old_log_probs, const float *advantages, const float *returns,
+                          const float *values, const float *old_values, int B, float clip_eps, float vf_coef, float ent_coef,
+                          int value_clip, int dense, int want_grad, float *dfeat, float *dW, float *dbias, float *dvalues,
+                          float *stats, float *row_logp, float *row_entropy, void *workspace, hipStream_t st) {
+    const HeadWs w = head_ws(workspace, B, K, dense);
+    KshHeadArgs a;
+    memset(&a, 0, sizeof a);
+    a.feat = feat; a.W = W; a.bias = bias; a.K = K; a.mask_bits = mask_bits; a.B = B;
+    KshLossArgs &L = a.L;
+    L.mask = nullptr;
+    L.mask_bits = mask_bits;
+    L.actions = reinterpret_cast<const long long *>(actions);
+    L.old_logp = old_log_probs; L.adv = advantages; L.ret = returns; L.values = values; L.old_values = old_values;
+    L.B = B; L.clip_eps = clip_eps; L.vf_coef = vf_coef; L.ent_coef = ent_coef; L.value_clip = value_clip;
+    L.dvalues = dvalues; L.stats = stats; L.partial = w.partial; L.only_overflow = 1;
+    L.row_logp = row_logp; L.row_entropy = row_entropy;
+    L.overflow_is_error = dense ? 0 : 1;
+    a.want_grad = want_grad;
+    a.dfeat = dfeat; a.dzT = w.dzT; a.bitsT = w.bitsT; a.BW = w.BW; a.n_over = w.n_over;
+    // the dense-row counter and (for the backward) the transposed bit matrix start from zero
+    HIP_TRY(hipMemsetAsync(w.n_over, 0, 64, st));
+    if (want_grad) HIP_TRY(hipMemsetAsync(w.bitsT, 0, (size_t)KSH_PA * w.BW * 4, st));
+    const dim3 grid((B + KSH_HEAD_WPB - 1) / KSH_HEAD_WPB), block(64 * KSH_HEAD_WPB);
+    if (K <= 192) hipLaunchKernelGGL(ksh_head_loss_kernel<192>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(ksh_head_loss_kernel<1312>, grid, block, 0, st, a);
+    KshGemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.flags = w.partial + 6;
+    g.n_over = w.n_over;
+    const dim3 gb(256);
+    if (dense) {
+        // dense rows, forward: logits[r][a] = <feat_r, W_a> + bias_a on the matrix cores, then the block-per-row kernel
+        g.mode = 0;
+        g.A = feat; g.sAm = K; g.sAk = 1;
+        g.Bm = W; g.sBk = 1; g.sBn = K;
+        g.C = w.zbuf; g.sCm = KSH_PA;
+        g.M = B; g.N = KSH_PA; g.Kd = K; g.bias = bias;
+        hipLaunchKernelGGL(ksh_head_gemm_kernel, dim3((B + 63) / 64, (KSH_PA + 63) / 64), gb, 0, st, g);
+        hipLaunchKernelGGL(ksh_ppo_loss_kernel<float>, dim3(B), dim3(KSH_ROW_THREADS), 0, st, L, (const float *)w.zbuf,
+                           want_grad ? w.dlbuf : (float *)nullptr);
+    }
+    if (want_grad) {
+        KshHeadDwArgs d;
+        d.feat = feat; d.dzT = w.dzT; d.bitsT = w.bitsT; d.dW = dW; d.dbias = dbias;
+        d.B = B; d.BW = w.BW; d.K = K; d.A = KSH_PA;
+        d.SEGW = w.SEGW; d.NSEG = w.NSEG; d.n_items = w.n_items; d.items = w.items; d.table = w.table;
+        d.partial = w.prow; d.partial_dz = w.pdz;
+        d.light_max = 64;
+        const dim3 ag((KSH_PA + KSH_DW_WPB - 1) / KSH_DW_WPB), ab(64 * KSH_DW_WPB);
+        hipLaunchKernelGGL(ksh_head_dw_scan_kernel, dim3((KSH_PA + KSH_DW_SCAN_WPB - 1) / KSH_DW_SCAN_WPB),
+                           dim3(64 * KSH_DW_SCAN_WPB), 0, st, d);
+        // a fixed grid walks the work list (its length is only known on the device): 2048 blocks = 8192 waves
+        if (K <= 192) {
+            hipLaunchKernelGGL(ksh_head_dw_work_kernel<192>, dim3(2048), ab, 0, st, d);
+            hipLaunchKernelGGL(ksh_head_dw_combine_kernel<192>, ag, ab, 0, st, d);
+        } else {
+            hipLaunchKernelGGL(ksh_head_dw_work_kernel<1312>, dim3(2048), ab, 0, st, d);
+            hipLaunchKernelGGL(ksh_head_dw_combine_kernel<1312>, ag, ab, 0, st, d);
+        }
+        if (dense) {
+            // dense rows, backward: dfeat_r = dl_r W ; dW += dl^T feat and dbias += column sums over the dense rows
+            g.mode = 1;
+            g.A = w.dlbuf; g.sAm = KSH_PA; g.sAk = 1;
+            g.Bm = W; g.sBk = K; g.sBn = 1;
+            g.C = dfeat; g.sCm = K;
+            g.M = B; g.N = K; g.Kd = KSH_PA; g.bias = nullptr;
+            hipLaunchKernelGGL(ksh_head_gemm_kernel, dim3((B + 63) / 64, (K + 63) / 64), gb, 0, st, g);
+            g.mode = 2;
+            g.A = w.dlbuf; g.sAm = 1; g.sAk = KSH_PA;
+            g.Bm = feat; g.sBk = K; g.sBn = 1;
+            g.C = dW; g.sCm = K; g.C2 = dbias;
+            g.M = KSH_PA; g.N = K + 1; g.Kd = B;
+            hipLaunchKernelGGL(ksh_head_gemm_kernel, dim3((KSH_PA + 63) / 64, (K + 1 + 63) / 64), gb, 0, st, g);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(ksh_ppo_stats_kernel, dim3(1), dim3(KSH_STATS_THREADS), 0, st, L);
+    HIP_TRY(hipGetLastError());
+    return KSH_OK;
+}
+
+int ksh_policy_head_loss_fwd_bwd(const float *feat, const float *W, const float *bias, int K, const uint32_t *mask_bits,
+                                 const int64_t *actions, const float *old_log_probs, const float *advantages,
+                                 const float *returns, const float *values, const float *old_values, int B, float clip_eps,
+                                 float vf_coef, float ent_coef, int value_clip, int dense_rows_possible, float *dfeat, float *dW,
+                                 float *dbias, float *dvalues, float *stats, void *workspace, void *stream) {
+    if (!head_common_ok("ksh_policy_head_loss_fwd_bwd", feat, W, K, mask_bits, B)) return KSH_E_ARG;
+    if (!actions || !old_log_probs || !advantages || !returns || !values || !dfeat || !dW || !dvalues || !stats || !workspace)
+        return fail_arg("ksh_policy_head_loss_fwd_bwd: null pointer");
+    if (value_clip && !old_values) return fail_arg("ksh_policy_head_loss_fwd_bwd: value_clip needs old_values");
+    if ((reinterpret_cast<size_t>(dfeat) & 7) != 0 || (reinterpret_cast<size_t>(workspace) & 255) != 0)
+        return fail_arg("ksh_policy_head_loss_fwd_bwd: dfeat must be 8-byte, workspace 256-byte aligned");
+    return head_loss_impl(feat, W, bias, K, mask_bits, actions, old_log_probs, advantages, returns, values, old_values, B, clip_eps,
+                          vf_coef, ent_coef, value_clip, dense_rows_possible, 1, dfeat, dW, dbias, dvalues, stats, nullptr, nullptr,
+                          workspace, (hipStream_t)stream);
+}
+
+uint64_t ksh_policy_head_evaluate_workspace_bytes(int B, int K, int dense_rows_possible) {
+    if (B <= 0 || K <= 0) return 0;
+    // the loss workspace minus the backward scratch is not worth a second layout: same function, plus per-row dummies
+    return ksh_policy_head_workspace_bytes(B, K, dense_rows_possible) + head_align((size_t)B * 8 + 64);
+}
+
+int ksh_policy_head_evaluate(const float *feat, const float *W, const float *bias, int K, const uint32_t *mask_bits,
+                             const int64_t *actions, int B, int dense_rows_possible, float *log_probs, float *entropy,
+                             void *workspace, void *stream) {
+    if (!head_common_ok("ksh_policy_head_evaluate", feat, W, K, mask_bits, B)) return KSH_E_ARG;
+    if (!actions || !log_probs || !entropy || !workspace) return fail_arg("ksh_policy_head_evaluate: null pointer");
+    if ((reinterpret_cast<size_t>(workspace) & 255) != 0) return fail_arg("ksh_policy_head_evaluate: workspace must be 256-byte aligned");
+    float *extra = (float *)((char *)workspace + ksh_policy_head_workspace_bytes(B, K, dense_rows_possible));
+    float *zeros = extra, *dval = extra + B;        // loss-only inputs read zeros; dvalues / stats are discarded
+    HIP_TRY(hipMemsetAsync(zeros, 0, (size_t)B * sizeof(float), (hipStream_t)stream));
+    float *stats = dval + B;
+    return head_loss_impl(feat, W, bias, K, mask_bits, actions, zeros, zeros, zeros, zeros, nullptr, B, 0.2f, 0.0f, 0.0f, 0,
+                          dense_rows_possible, 0, nullptr, nullptr, nullptr, dval, stats, log_probs, entropy, workspace,
+                          (hipStream_t)stream);
 }
 
 #ifdef KSH_STAMPS

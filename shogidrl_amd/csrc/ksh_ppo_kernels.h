@@ -386,6 +386,7 @@ struct KshLossArgs {
     int only_overflow;  // dense kernel: process only the rows the sparse kernel flagged (partial[b][6] != 0)
     float *row_logp;     // [B] or null: log-prob of actions[b] under the masked soft-max (evaluate_actions' first output)
     float *row_entropy;  // [B] or null: entropy of the row's distribution (evaluate_actions' second output)
+    int overflow_is_error;  // stats kernel: a row still flagged in partial[b][6] (dense row, dense path switched off) poisons the outputs with NaN
 };
 
 template <typename T>
@@ -461,7 +462,7 @@ ksh_ppo_loss_kernel(KshLossArgs a, const T *__restrict__ logits, T *__restrict__
         p[3] = H;
         p[4] = old_lp - new_logp;
         p[5] = (fabsf(ratio - 1.0f) > a.clip_eps) ? 1.0f : 0.0f;
-        p[6] = 0.0f;
+        if (!a.only_overflow) p[6] = 0.0f;   // a flagged row stays flagged: the fused head's backward GEMMs gate on it
         p[7] = 0.0f;
         if (a.row_logp != nullptr) a.row_logp[b] = new_logp;
         if (a.row_entropy != nullptr) a.row_entropy[b] = H;
@@ -703,20 +704,27 @@ ksh_ppo_loss_sparse_kernel(KshLossArgs a, const T *__restrict__ logits, T *__res
 }
 
 // Batch means, the value-loss branch (max of the two MEANS, ppo_agent.py:357-373) and d(loss)/d(values).
-extern "C" __global__ void ksh_ppo_stats_kernel(KshLossArgs a) {
-    __shared__ float red[256][6];
+// One block of KSH_STATS_THREADS threads (any power of two up to that works); fixed-order tree reduction.
+#define KSH_STATS_THREADS 1024
+extern "C" __global__ void __launch_bounds__(KSH_STATS_THREADS) ksh_ppo_stats_kernel(KshLossArgs a) {
+    __shared__ float red[KSH_STATS_THREADS][6];
     __shared__ float tot[6];
-    const int tid = threadIdx.x;
+    __shared__ int bad;
+    const int tid = threadIdx.x, nt = (int)blockDim.x;
     float acc[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = tid; i < a.B; i += 256) {
-        const float *p = a.partial + (size_t)i * 8;
-#pragma unroll
-        for (int k = 0; k < 6; k++) acc[k] += p[k];
+    int flagged = 0;
+    for (int i = tid; i < a.B; i += nt) {
+        const float4 *p = reinterpret_cast<const float4 *>(a.partial + (size_t)i * 8);   // rows are 32 bytes
+        const float4 u = p[0], v = p[1];
+        acc[0] += u.x; acc[1] += u.y; acc[2] += u.z; acc[3] += u.w; acc[4] += v.x; acc[5] += v.y;
+        flagged |= v.z != 0.0f;
     }
 #pragma unroll
     for (int k = 0; k < 6; k++) red[tid][k] = acc[k];
+    if (tid == 0) bad = 0;
     __syncthreads();
-    for (int o = 128; o >= 1; o >>= 1) {
+    if (flagged) bad = 1;
+    for (int o = nt >> 1; o >= 1; o >>= 1) {
         if (tid < o) {
 #pragma unroll
             for (int k = 0; k < 6; k++) red[tid][k] += red[tid + o][k];
@@ -725,6 +733,13 @@ extern "C" __global__ void ksh_ppo_stats_kernel(KshLossArgs a) {
     }
     if (tid < 6) tot[tid] = red[0][tid] / (float)a.B;
     __syncthreads();
+    if (a.overflow_is_error && bad) {
+        // the caller promised sparse rows (<= 1024 legal actions) and skipped the dense path: a flagged row was never
+        // evaluated, so nothing computed from this minibatch may look valid
+        if (tid < 8) a.stats[tid] = NAN;
+        for (int i = tid; i < a.B; i += nt) a.dvalues[i] = NAN;
+        return;
+    }
     const float policy_loss = -tot[0];
     const float vu = tot[1], vc = tot[2];
     float wu = 1.0f, wc = 0.0f;  // weights of the unclipped / clipped branch in d value_loss
@@ -747,7 +762,7 @@ extern "C" __global__ void ksh_ppo_stats_kernel(KshLossArgs a) {
         a.stats[7] = 0.0f;
     }
     const float k2 = a.vf_coef * 2.0f / (float)a.B;
-    for (int i = tid; i < a.B; i += 256) {
+    for (int i = tid; i < a.B; i += nt) {
         const float V = a.values[i], Rt = a.ret[i];
         float g = wu * k2 * (V - Rt);
         if (a.value_clip && wc != 0.0f) {

@@ -21,6 +21,16 @@ class TinyActorCritic(nn.Module):
         self.policy_head = nn.Linear(16 * 81, num_actions_total)
         self.value_head = nn.Linear(16 * 81, 1)
 
+    @property
+    def policy_linear(self):
+        """the last layer of the policy head: the fused head kernels take its weight / bias and its INPUT features"""
+        return self.policy_head
+
+    def policy_features(self, x):
+        """(input of policy_linear [B,1296] float32, value [B]): forward() without the last Linear of the policy head"""
+        h = torch.flatten(F.relu(self.conv(x)), 1).float()
+        return h, self.value_head(h).squeeze(-1)
+
     def forward(self, x):
         h = torch.flatten(F.relu(self.conv(x)), 1)
         return self.policy_head(h), self.value_head(h).squeeze(-1)
@@ -119,6 +129,24 @@ class ResTowerActorCritic(nn.Module):
 
     def trunk(self, x):
         return self.res_blocks(_conv_bn(self.stem, self.bn_stem, x, relu=True))
+
+    @property
+    def policy_linear(self):
+        """nn.Linear(2*9*9, 13527) (resnet_tower.py:63-69): the layer the fused head kernels absorb"""
+        return self.policy_head[4]
+
+    def policy_features(self, x):
+        """(input of policy_linear [B,162] float32, value [B]) -- forward() minus the policy head's last Linear; the
+        agent hands these features to ops.policy_head_* so that the [B,13527] logits are never materialised"""
+        h = self.trunk(x)
+        p, v = self.policy_head[0](h), self.value_head[0](h)
+        with torch.autocast(device_type=x.device.type, enabled=False):
+            p, v = p.float(), v.float()
+            for layer in list(self.policy_head)[1:4]:
+                p = layer(p)
+            for layer in list(self.value_head)[1:]:
+                v = layer(v)
+            return p, v.squeeze(-1)
 
     def forward(self, x):
         h = self.trunk(x)

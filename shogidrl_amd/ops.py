@@ -4,6 +4,9 @@
   gae             <- ExperienceBuffer.compute_advantages_and_returns (keisei/core/experience_buffer.py:99-145)
   ppo_loss        <- evaluate_actions tail + PPOAgent.learn loss lines (base_actor_critic.py:147-184,
                      keisei/core/ppo_agent.py:340-383), forward and backward fused in one kernel
+  policy_head_*   <- the same three tails FUSED with the policy head's last nn.Linear (training/models/resnet_tower.py:63-69):
+                     they take the Linear's input features + weight + bias instead of logits; logits [B,13527] and their
+                     gradient never exist in memory (csrc/ksh_head_kernels.h)
 """
 import torch
 
@@ -175,3 +178,141 @@ def ppo_loss(logits, values, legal_mask, actions, old_log_probs, advantages, ret
         raise TypeError("actions must be int64")
     return _PPOLossFn.apply(logits, values, legal_mask, actions, old_log_probs, advantages, returns, old_values,
                             clip_eps, vf_coef, ent_coef, value_clip)
+
+
+# ---------------------------------------------------------------------------------------------- fused policy head
+def pack_mask_bits(mask):
+    """bool / uint8 [B,13527] -> int32 [B,424] by the HIP kernel (pack_mask above is the torch helper for tests)"""
+    _need_cuda(mask)
+    mask = _mask_u8(mask)
+    B = mask.shape[0]
+    assert mask.shape == (B, NUM_ACTIONS)
+    bits = torch.empty((B, MASK_WORDS), dtype=torch.int32, device=mask.device)
+    check(lib().ksh_pack_mask(mask.data_ptr(), B, bits.data_ptr(), _stream()), "ksh_pack_mask")
+    return bits
+
+
+def _head_args(feat, weight, bias, legal_mask):
+    _need_cuda(feat, weight, bias, legal_mask)
+    if feat.dtype != torch.float32 or weight.dtype != torch.float32 or (bias is not None and bias.dtype != torch.float32):
+        raise TypeError("the fused policy head runs in float32 (features, weight and bias)")
+    B, K = feat.shape
+    if weight.shape != (NUM_ACTIONS, K) or (bias is not None and bias.shape != (NUM_ACTIONS,)):
+        raise ValueError("weight must be [13527, K] and bias [13527] for features [B, K]")
+    if K % 2 or K > 1312:
+        raise ValueError("the fused policy head needs an even K <= 1312, got %d" % K)
+    bits = legal_mask.contiguous() if is_packed(legal_mask) else pack_mask_bits(legal_mask)
+    if bits.shape != (B, MASK_WORDS):
+        raise ValueError("legal mask must have one row per feature row")
+    return feat.contiguous(), weight.contiguous(), None if bias is None else bias.contiguous(), bits, B, K
+
+
+def policy_head_sample(feat, weight, bias, legal_mask, seed, step, deterministic=False):
+    """get_action_and_value's tail fused with the policy head's Linear layer: feat [B,K] float32, weight [13527,K], bias
+    [13527] or None, legal_mask bool [B,13527] or packed int32 [B,424] -> (action int64 [B], log_prob [B]).  Same RNG
+    stream and results as masked_sample(feat @ weight.T + bias, ...) up to float32 summation order of the logits.
+    `step`: Python int or a one-element int64 CUDA tensor (hipGraph-captured rollouts)."""
+    feat, weight, bias, bits, B, K = _head_args(feat, weight, bias, legal_mask)
+    action = torch.empty(B, dtype=torch.int64, device=feat.device)
+    logp = torch.empty(B, dtype=torch.float32, device=feat.device)
+    step_dev = None
+    if isinstance(step, torch.Tensor):
+        if step.dtype != torch.int64 or step.numel() != 1 or step.device != feat.device:
+            raise TypeError("a device step counter must be a one-element int64 tensor on the features' device")
+        step_dev, step = step.data_ptr(), 0
+    check(lib().ksh_policy_head_sample(feat.data_ptr(), weight.data_ptr(), None if bias is None else bias.data_ptr(), K,
+                                       bits.data_ptr(), B, int(seed), int(step), step_dev, int(bool(deterministic)),
+                                       action.data_ptr(), logp.data_ptr(), _stream()), "ksh_policy_head_sample")
+    return action, logp
+
+
+def policy_head_evaluate(feat, weight, bias, legal_mask, actions, dense_rows_possible=True):
+    """evaluate_actions' tail fused with the Linear layer, no gradient: (log_probs [B], entropy [B])."""
+    feat, weight, bias, bits, B, K = _head_args(feat, weight, bias, legal_mask)
+    if actions.dtype != torch.int64:
+        raise TypeError("actions must be int64")
+    logp = torch.empty(B, dtype=torch.float32, device=feat.device)
+    ent = torch.empty(B, dtype=torch.float32, device=feat.device)
+    L = lib()
+    d = int(bool(dense_rows_possible))
+    ws = torch.empty(int(L.ksh_policy_head_evaluate_workspace_bytes(B, K, d)), dtype=torch.uint8, device=feat.device)
+    check(L.ksh_policy_head_evaluate(feat.data_ptr(), weight.data_ptr(), None if bias is None else bias.data_ptr(), K,
+                                     bits.data_ptr(), actions.contiguous().data_ptr(), B, d, logp.data_ptr(), ent.data_ptr(),
+                                     ws.data_ptr(), _stream()), "ksh_policy_head_evaluate")
+    return logp, ent
+
+
+@torch.no_grad()
+def policy_head_loss_grads(feat, weight, bias, values, legal_mask, actions, old_log_probs, advantages, returns, old_values=None,
+                           clip_eps=0.2, vf_coef=0.5, ent_coef=0.01, value_clip=False, dense_rows_possible=True,
+                           out_dweight=None, out_dbias=None):
+    """The fused head's forward + backward as a plain function (no autograd node): returns
+    (stats [8], dfeat [B,K], dweight [13527,K], dbias [13527] | None, dvalues [B]) = the loss terms and d loss / d input.
+    out_dweight / out_dbias: dense float32 tensors the kernels write the parameter gradients into (e.g. views of a flat
+    all-reduce bucket), so that no copy or scaling pass touches the 8.8 MB weight gradient afterwards."""
+    if value_clip and old_values is None:
+        raise ValueError("value_clip=True needs old_values")
+    if actions.dtype != torch.int64:
+        raise TypeError("actions must be int64")
+    feat_c, weight_c, bias_c, bits, B, K = _head_args(feat, weight, bias, legal_mask)
+    values_c = values.contiguous().float()
+    f = lambda t: t.contiguous().float()
+    dev = feat.device
+    dfeat = torch.empty_like(feat_c)
+    dW = out_dweight if out_dweight is not None else torch.empty_like(weight_c)
+    if dW.shape != weight_c.shape or dW.dtype != torch.float32 or not dW.is_contiguous():
+        raise ValueError("out_dweight must be a contiguous float32 tensor shaped like weight")
+    dbias = None
+    if bias is not None:
+        dbias = out_dbias if out_dbias is not None else torch.empty(NUM_ACTIONS, dtype=torch.float32, device=dev)
+        if dbias.shape != (NUM_ACTIONS,) or dbias.dtype != torch.float32 or not dbias.is_contiguous():
+            raise ValueError("out_dbias must be a contiguous float32 tensor of 13527 elements")
+    dvalues = torch.empty(B, dtype=torch.float32, device=dev)
+    stats = torch.empty(8, dtype=torch.float32, device=dev)
+    L = lib()
+    d = int(bool(dense_rows_possible))
+    ws = torch.empty(int(L.ksh_policy_head_workspace_bytes(B, K, d)), dtype=torch.uint8, device=dev)
+    ov = f(old_values) if old_values is not None else None
+    check(L.ksh_policy_head_loss_fwd_bwd(
+        feat_c.data_ptr(), weight_c.data_ptr(), None if bias_c is None else bias_c.data_ptr(), K, bits.data_ptr(),
+        actions.contiguous().data_ptr(), f(old_log_probs).data_ptr(), f(advantages).data_ptr(), f(returns).data_ptr(),
+        values_c.data_ptr(), ov.data_ptr() if ov is not None else None, B, float(clip_eps), float(vf_coef), float(ent_coef),
+        int(bool(value_clip)), d, dfeat.data_ptr(), dW.data_ptr(), None if dbias is None else dbias.data_ptr(),
+        dvalues.data_ptr(), stats.data_ptr(), ws.data_ptr(), _stream()), "ksh_policy_head_loss_fwd_bwd")
+    return stats, dfeat, dW, dbias, dvalues
+
+
+class _HeadLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, weight, bias, values, legal_mask, actions, old_log_probs, advantages, returns, old_values, clip_eps,
+                vf_coef, ent_coef, value_clip, dense):
+        stats, dfeat, dW, dbias, dvalues = policy_head_loss_grads(feat, weight, bias, values, legal_mask, actions, old_log_probs,
+                                                                  advantages, returns, old_values, clip_eps, vf_coef, ent_coef,
+                                                                  value_clip, dense)
+        ctx.save_for_backward(dfeat, dW, dvalues, *([dbias] if dbias is not None else []))
+        ctx.has_bias = dbias is not None
+        ctx.values_dtype = values.dtype
+        ctx.mark_non_differentiable(stats)
+        return stats[0].clone(), stats
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_stats):
+        saved = ctx.saved_tensors
+        dfeat, dW, dvalues = saved[0], saved[1], saved[2]
+        dbias = saved[3] if ctx.has_bias else None
+        g = grad_loss
+        # the kernels produced d loss / d inputs; autograd's incoming gradient is a scalar (1.0 when loss.backward())
+        return (dfeat * g, dW * g, None if dbias is None else dbias * g, (dvalues * g).to(ctx.values_dtype)) + (None,) * 11
+
+
+def policy_head_ppo_loss(feat, weight, bias, values, legal_mask, actions, old_log_probs, advantages, returns, old_values=None,
+                         clip_eps=0.2, vf_coef=0.5, ent_coef=0.01, value_clip=False, dense_rows_possible=True):
+    """ppo_loss with logits = feat @ weight.T + bias never materialised.  Returns (loss, stats); `loss` is differentiable
+    w.r.t. feat, weight, bias and values.  dense_rows_possible=False skips the dense (MFMA) path and its scratch -- only
+    for masks produced by the env kernel (<= 593 legal actions per row); a dense row then makes the loss NaN."""
+    if value_clip and old_values is None:
+        raise ValueError("value_clip=True needs old_values")
+    if actions.dtype != torch.int64:
+        raise TypeError("actions must be int64")
+    return _HeadLossFn.apply(feat, weight, bias, values, legal_mask, actions, old_log_probs, advantages, returns, old_values,
+                             clip_eps, vf_coef, ent_coef, value_clip, dense_rows_possible)

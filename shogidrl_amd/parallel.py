@@ -94,6 +94,14 @@ class FlatGradBucket:
         for p in self.params:
             p.grad = None
 
+    def view_of(self, param):
+        """the slice of the flat buffer that holds `param`'s gradient (same sizes and strides as the parameter): a kernel
+        may write a gradient straight into it; assign it to param.grad afterwards and gather() leaves it alone"""
+        for p, v in zip(self.params, self.views):
+            if p is param:
+                return v
+        raise KeyError("parameter is not in this bucket")
+
     def gather(self):
         """After backward(): move every gradient into the flat buffer with one multi-tensor copy and point .grad at the
         views again (the optimizer and the all-reduce work on the flat buffer)."""
@@ -101,6 +109,8 @@ class FlatGradBucket:
         for p, v in zip(self.params, self.views):
             if p.grad is None:
                 v.zero_()                      # parameter not reached by this backward
+            elif p.grad is v:
+                pass                           # written in place (view_of): nothing to move
             elif p.grad.dtype == v.dtype:
                 dst.append(v)
                 src.append(p.grad)

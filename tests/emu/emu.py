@@ -126,6 +126,11 @@ def _plib():
                                     C.c_void_p, C.c_void_p]
     L.emu_ppo_loss.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_float, C.c_float, C.c_float,
                                                                           C.c_int] + [C.c_void_p] * 4
+    vp, i32, f32, u64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64
+    L.emu_pack_mask.argtypes = [vp, i32, vp]
+    L.emu_head_sample.argtypes = [vp, vp, vp, i32, vp, i32, u64, u64, i32, vp, vp]
+    L.emu_head_loss.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, i32, i32, i32,
+                                vp, vp, vp, vp, vp, vp, vp, i32, i32]
     L.emu_evaluate_actions.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     return L
 
@@ -199,6 +204,54 @@ class EmuOps:
         _plib().emu_evaluate_actions(lg.ctypes.data, 0, None if self.packed else m8.ctypes.data,
                                      None if bits is None else bits.ctypes.data, a64.ctypes.data, B, lp.ctypes.data, en.ctypes.data)
         return lp, en
+
+
+    # ---- fused policy head (ksh_head_kernels.h); masks are always handed over bit-packed
+    wpa = 0          # max segments per bit row in the weight-gradient pipeline (0 = the library's choice)
+    light_max = -1   # actions with at most this many samples are one work item (-1 = the library's 64)
+
+    def pack_mask_kernel(self, mask):
+        m8 = np.ascontiguousarray(mask, np.uint8)
+        bits = np.full((m8.shape[0], 424), 0xDEADBEEF, np.uint32)
+        _plib().emu_pack_mask(m8.ctypes.data, m8.shape[0], bits.ctypes.data)
+        return bits
+
+    def head_sample(self, feat, W, bias, mask, seed, step, deterministic):
+        f = lambda x: None if x is None else np.ascontiguousarray(x, np.float32)
+        feat, W, bias = f(feat), f(W), f(bias)
+        B, K = feat.shape
+        bits = pack_mask(mask)
+        act = np.zeros(B, np.int64); lp = np.zeros(B, np.float32)
+        _plib().emu_head_sample(feat.ctypes.data, W.ctypes.data, None if bias is None else bias.ctypes.data, K, bits.ctypes.data,
+                                B, seed, step, int(deterministic), act.ctypes.data, lp.ctypes.data)
+        return act, lp
+
+    def _head(self, feat, W, bias, mask, actions, old_logp, adv, ret, values, old_values, clip_eps, vf, ent, value_clip,
+              dense, want_grad):
+        f = lambda x: None if x is None else np.ascontiguousarray(x, np.float32)
+        feat, W, bias = f(feat), f(W), f(bias)
+        B, K = feat.shape
+        bits = pack_mask(mask)
+        a64 = np.ascontiguousarray(actions, np.int64)
+        ol, ad, rt, vl, ov = f(old_logp), f(adv), f(ret), f(values), f(old_values)
+        dfeat = np.full((B, K), np.nan, np.float32); dW = np.full(W.shape, np.nan, np.float32)
+        dbias = np.full(W.shape[0], np.nan, np.float32)
+        dv = np.zeros(B, np.float32); st = np.zeros(8, np.float32)
+        lp = np.full(B, np.nan, np.float32); en = np.full(B, np.nan, np.float32)
+        p = lambda x: None if x is None else x.ctypes.data
+        _plib().emu_head_loss(p(feat), p(W), p(bias), K, p(bits), p(a64), p(ol), p(ad), p(rt), p(vl), p(ov), B, clip_eps, vf, ent,
+                              int(value_clip), int(dense), int(want_grad), p(dfeat), p(dW), p(dbias), p(dv), p(st), p(lp), p(en),
+                              int(self.wpa), int(self.light_max))
+        return dfeat, dW, dbias, dv, st, lp, en
+
+    def head_loss(self, feat, W, bias, mask, actions, old_logp, adv, ret, values, old_values, clip_eps, vf, ent, value_clip,
+                  dense=True):
+        return self._head(feat, W, bias, mask, actions, old_logp, adv, ret, values, old_values, clip_eps, vf, ent, value_clip,
+                          dense, 1)[:5]
+
+    def head_evaluate(self, feat, W, bias, mask, actions, dense=True):
+        z = np.zeros(feat.shape[0], np.float32)
+        return self._head(feat, W, bias, mask, actions, z, z, z, z, None, 0.2, 0.0, 0.0, 0, dense, 0)[5:]
 
 
 # ------------------------------------------------------------------ tower-glue kernels

@@ -66,3 +66,5 @@ void emu_evaluate_actions(const void *logits, int dtype, const uint8_t *mask, co
     g_row_logp = nullptr; g_row_entropy = nullptr;
 }
 }
+
+#include "emu_head.inc"

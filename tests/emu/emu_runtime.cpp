@@ -3,6 +3,7 @@
 
 namespace emu {
 Block *B = nullptr;
+EmuDim3 g_grid = {1, 1, 1};
 static const size_t STACK = 256 * 1024;
 
 static void trampoline() {
@@ -28,7 +29,7 @@ static void die(const char *msg, int wave) {
     abort();
 }
 
-void run_block(void (*entry)(void *), void *arg, int block_idx, int nthreads) {
+void run_block(void (*entry)(void *), void *arg, int block_idx, int nthreads, int block_idy) {
     static Block blk;
     static Lane *lanes = nullptr;
     static int cap = 0;
@@ -40,7 +41,7 @@ void run_block(void (*entry)(void *), void *arg, int block_idx, int nthreads) {
     B = &blk;
     blk.nthreads = nthreads;
     blk.lanes = lanes;
-    blk.bidx = EmuDim3{block_idx, 0, 0};
+    blk.bidx = EmuDim3{block_idx, block_idy, 0};
     blk.bdim = EmuDim3{nthreads, 1, 1};
     blk.entry = entry;
     blk.entry_arg = arg;
@@ -87,6 +88,20 @@ void run_block(void (*entry)(void *), void *arg, int block_idx, int nthreads) {
                 uint64_t m = 0;
                 for (int i = lo; i < hi; i++) if (lanes[i].arg) m |= 1ull << (i - lo);
                 for (int i = lo; i < hi; i++) lanes[i].res = m;
+            } else if (op == OP_MFMA32) {
+                if (hi - lo != 64) die("MFMA needs a full wave", w);
+                float A[32][2], Bm[2][32];
+                MfmaOperands *o[64];
+                for (int l = 0; l < 64; l++) {
+                    o[l] = (MfmaOperands *)(uintptr_t)lanes[lo + l].arg;
+                    A[l & 31][l >> 5] = o[l]->a;
+                    Bm[l >> 5][l & 31] = o[l]->b;
+                }
+                for (int l = 0; l < 64; l++)
+                    for (int r = 0; r < 16; r++) {
+                        const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), j = l & 31;
+                        o[l]->acc[r] = fmaf(A[i][1], Bm[1][j], fmaf(A[i][0], Bm[0][j], o[l]->acc[r]));
+                    }
             } else if (op == OP_SHFL) {
                 uint64_t vals[64];
                 for (int i = lo; i < hi; i++) vals[i - lo] = lanes[i].arg;

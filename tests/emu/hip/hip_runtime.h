@@ -28,7 +28,8 @@ static inline float2 make_float2(float a, float b) { return float2{a, b}; }
 struct EmuDim3 { int x, y, z; };
 
 namespace emu {
-enum Op { OP_NONE = 0, OP_BALLOT, OP_SHFL, OP_WAVE_BARRIER, OP_SYNCTHREADS };
+enum Op { OP_NONE = 0, OP_BALLOT, OP_SHFL, OP_WAVE_BARRIER, OP_SYNCTHREADS, OP_MFMA32 };
+struct MfmaOperands { float a, b; float *acc; };
 struct Lane {
     ucontext_t ctx;
     char *stack;
@@ -51,15 +52,19 @@ struct Block {
 extern Block *B;
 inline Lane &me() { return B->lanes[B->cur]; }
 uint64_t park(int op, uint64_t arg, int arg2);
-void run_block(void (*entry)(void *), void *arg, int block_idx, int nthreads);
+void run_block(void (*entry)(void *), void *arg, int block_idx, int nthreads, int block_idy = 0);
 inline EmuDim3 tid() { return EmuDim3{B->lanes[B->cur].tid, 0, 0}; }
 inline EmuDim3 bid() { return B->bidx; }
 inline EmuDim3 bdim() { return B->bdim; }
+extern EmuDim3 g_grid;
+inline void set_grid_dim(int x, int y = 1) { g_grid = EmuDim3{x, y, 1}; }
+inline EmuDim3 gdim() { return g_grid; }
 }  // namespace emu
 
 #define threadIdx (emu::tid())
 #define blockIdx (emu::bid())
 #define blockDim (emu::bdim())
+#define gridDim (emu::gdim())
 
 static inline unsigned long long __ballot(int pred) { return emu::park(emu::OP_BALLOT, pred ? 1 : 0, 0); }
 template <class T> static inline T __shfl(T v, int src) {
@@ -117,3 +122,17 @@ struct bf16 {
 static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_readlane(x, l) (__shfl((int)(x), (l)))
+// v_mfma_f32_32x32x2_f32: one rendez-vous of the wave; the scheduler computes D = A(32x2) B(2x32) + C for all lanes with
+// the hardware's lane maps (A[i = l & 31][k = l >> 5], B[k = l >> 5][j = l & 31], D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)]
+// [col = l & 31] in register r) and its arithmetic (a k-ordered fmaf chain).
+typedef float emu_f32x16 __attribute__((vector_size(64)));
+static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, emu_f32x16 c, int, int, int) {
+    float acc[16];
+    for (int r = 0; r < 16; r++) acc[r] = c[r];
+    emu::MfmaOperands ops = {a, b, acc};
+    (void)emu::park(emu::OP_MFMA32, (uint64_t)(uintptr_t)&ops, 0);
+    emu_f32x16 d;
+    for (int r = 0; r < 16; r++) d[r] = acc[r];
+    return d;
+}

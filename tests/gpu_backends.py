@@ -107,6 +107,40 @@ class GpuOps:
         return lp.cpu().numpy(), en.cpu().numpy()
 
 
+    # ---- fused policy head (masks go in as bool rows; the op packs them with the HIP kernel)
+    def pack_mask_kernel(self, mask):
+        return ops.pack_mask_bits(torch.as_tensor(np.asarray(mask, np.uint8), device=DEV)).cpu().numpy().view(np.uint32)
+
+    @staticmethod
+    def _hf(x):
+        return None if x is None else torch.as_tensor(np.ascontiguousarray(x, np.float32), device=DEV)
+
+    def head_sample(self, feat, W, bias, mask, seed, step, deterministic):
+        act, lp = ops.policy_head_sample(self._hf(feat), self._hf(W), self._hf(bias),
+                                         torch.as_tensor(np.asarray(mask, bool), device=DEV), seed, step, deterministic)
+        return act.cpu().numpy(), lp.cpu().numpy()
+
+    def head_evaluate(self, feat, W, bias, mask, actions, dense=True):
+        lp, en = ops.policy_head_evaluate(self._hf(feat), self._hf(W), self._hf(bias),
+                                          torch.as_tensor(np.asarray(mask, bool), device=DEV),
+                                          torch.as_tensor(np.asarray(actions, np.int64), device=DEV), dense)
+        return lp.cpu().numpy(), en.cpu().numpy()
+
+    def head_loss(self, feat, W, bias, mask, actions, old_logp, adv, ret, values, old_values, clip_eps, vf, ent, value_clip,
+                  dense=True):
+        ft = self._hf(feat).requires_grad_(True)
+        Wt = self._hf(W).requires_grad_(True)
+        bt = None if bias is None else self._hf(bias).requires_grad_(True)
+        vl = self._hf(values).requires_grad_(True)
+        loss, stats = ops.policy_head_ppo_loss(ft, Wt, bt, vl, torch.as_tensor(np.asarray(mask, bool), device=DEV),
+                                               torch.as_tensor(np.asarray(actions, np.int64), device=DEV), self._hf(old_logp),
+                                               self._hf(adv), self._hf(ret), self._hf(old_values), clip_eps, vf, ent,
+                                               bool(value_clip), dense_rows_possible=dense)
+        loss.backward()
+        db = np.zeros(W.shape[0], np.float32) if bt is None else bt.grad.cpu().numpy()
+        return ft.grad.cpu().numpy(), Wt.grad.cpu().numpy(), db, vl.grad.cpu().numpy(), stats.cpu().numpy()
+
+
 class GpuTower:
     """numpy backend of tests/towercheck.py over the C-ABI tower entry points (dense [M, C] activations)."""
 

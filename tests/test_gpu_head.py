@@ -1,0 +1,141 @@
+"""The fused policy head on the MI355X through the C-ABI (ksh_policy_head_*): the reference's golden vectors, the
+float64 oracle, the MFMA dense path, and agreement with the logits-based kernels it replaces."""
+import numpy as np
+import pytest
+import torch
+
+from tests import headcheck
+
+pytestmark = pytest.mark.gpu
+A = 13527
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from tests.gpu_backends import GpuOps
+    return GpuOps()
+
+
+def test_gpu_pack_mask_kernel(ops):
+    headcheck.check_pack_mask(ops)
+
+
+def test_gpu_head_loss_golden_reference_autograd(ops):
+    headcheck.check_head_loss_golden(ops)
+
+
+@pytest.mark.parametrize("B,K,vc,dense,empty", [(5, 162, 0, 0, 0), (6, 162, 1, 1, 1), (3, 1296, 0, 0, 1), (130, 162, 0, 3, 2),
+                                                (64, 1296, 1, 2, 0)])
+def test_gpu_head_loss_vs_oracle(ops, B, K, vc, dense, empty):
+    headcheck.check_head_loss_vs_oracle(ops, B, K, seed=B + K, value_clip=vc, dense_rows=dense, empty_rows=empty)
+
+
+def test_gpu_head_loss_sparse_only_and_no_bias(ops):
+    headcheck.check_head_loss_vs_oracle(ops, 300, 162, seed=5, dense=False, with_bias=False)
+
+
+def test_gpu_head_dense_row_without_dense_path_is_loud(ops):
+    headcheck.check_head_dense_row_without_dense_path_is_loud(ops)
+
+
+def test_gpu_head_evaluate(ops):
+    headcheck.check_head_evaluate(ops)
+
+
+def test_gpu_head_sample_golden(ops):
+    headcheck.check_head_sample_golden(ops)
+
+
+def test_gpu_head_sample_vs_oracle(ops):
+    headcheck.check_head_sample_vs_oracle(ops)
+
+
+def test_gpu_head_sample_distribution(ops):
+    headcheck.check_head_sample_distribution(ops)
+
+
+def test_gpu_mfma_dense_path_all_rows_dense_equals_torch():
+    """every row dense (all-ones masks, as in the reference's unit tests): the whole op runs on the float32 MFMA GEMMs;
+    compared with plain PyTorch float32 autograd of the same arithmetic"""
+    from shogidrl_amd import ops as O
+    torch.manual_seed(0)
+    B, K = 96, 162
+    dev = "cuda:0"
+    feat = torch.randn(B, K, device=dev, requires_grad=True)
+    W = (torch.randn(A, K, device=dev) * 0.15).requires_grad_(True)
+    b = (torch.randn(A, device=dev) * 0.3).requires_grad_(True)
+    values = torch.randn(B, device=dev, requires_grad=True)
+    mask = torch.ones(B, A, dtype=torch.bool, device=dev)
+    actions = torch.randint(0, A, (B,), device=dev)
+    old_lp = torch.full((B,), -9.5, device=dev) + 0.1 * torch.randn(B, device=dev)
+    adv, ret = torch.randn(B, device=dev), torch.randn(B, device=dev)
+    loss, stats = O.policy_head_ppo_loss(feat, W, b, values, mask, actions, old_lp, adv, ret, None, 0.2, 0.5, 0.01, False)
+    loss.backward()
+    got = [feat.grad.clone(), W.grad.clone(), b.grad.clone(), values.grad.clone()]
+    for t in (feat, W, b, values):
+        t.grad = None
+    logits = feat @ W.t() + b
+    p = torch.softmax(logits, dim=1)
+    dist = torch.distributions.Categorical(probs=p)
+    new_lp, H = dist.log_prob(actions), dist.entropy()
+    ratio = torch.exp(new_lp - old_lp)
+    pl = -torch.min(ratio * adv, torch.clamp(ratio, 0.8, 1.2) * adv).mean()
+    vl = torch.nn.functional.mse_loss(values, ret)
+    ref = pl + 0.5 * vl + 0.01 * (-H.mean())
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 2e-5 * max(1.0, abs(float(ref)))
+    for g, t, name in zip(got, (feat, W, b, values), ("dfeat", "dW", "dbias", "dvalues")):
+        np.testing.assert_allclose(g.cpu().numpy(), t.grad.cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=name)
+
+
+@pytest.mark.parametrize("N", [4096, 8192])
+def test_gpu_fused_head_agrees_with_logits_kernels_on_self_play_masks(N):
+    """production shape: 4096 (and 8192: two 256-sample windows per segment) rows of real self-play masks, K = 162.  The fused sampler draws the same actions as the
+    logits-based sampler fed hipBLASLt logits (same Philox stream; float32 logit noise can only flip near-ties), and the
+    fused loss returns the gradients PyTorch's autograd derives from the logits-based loss kernel."""
+    from shogidrl_amd import ops as O
+    from shogidrl_amd.env import VecShogiEnv
+    torch.manual_seed(1)
+    K, dev = 162, "cuda:0"
+    env = VecShogiEnv(N, 500, device=dev)
+    env.reset()
+    zeros = torch.zeros(N, A, device=dev)
+    for t in range(30):                                        # desynchronise the games
+        a, _ = O.masked_sample(zeros, env.legal_bits, 3, t)
+        env.step(a)
+    bits, mask = env.legal_bits, env.legal_mask
+    assert int(env.n_legal.max()) <= 593
+    if N > 4096:
+        # one action legal in EVERY sample: a heavy action whose segments hold 512 samples each
+        mask = mask.clone()
+        mask[:, 77] = True
+        bits = O.pack_mask_bits(mask)
+    feat = torch.randn(N, K, device=dev)
+    W = torch.randn(A, K, device=dev) * 0.1
+    b = torch.randn(A, device=dev) * 0.1
+    logits = feat @ W.t() + b
+    a1, lp1 = O.policy_head_sample(feat, W, b, bits, 7, 5)
+    a2, lp2 = O.masked_sample(logits, bits, 7, 5)
+    same = a1 == a2
+    assert float(same.float().mean()) > 0.999
+    assert torch.allclose(lp1[same], lp2[same], atol=1e-5)
+    assert bool(mask.gather(1, a1[:, None]).all())
+    # loss + gradients
+    values = torch.randn(N, device=dev)
+    adv, ret = torch.randn(N, device=dev), torch.randn(N, device=dev)
+    f1, W1, b1, v1 = (t.clone().requires_grad_(True) for t in (feat, W, b, values))
+    loss1, st1 = O.policy_head_ppo_loss(f1, W1, b1, v1, bits, a1, lp1 - 0.1, adv, ret, None, 0.2, 0.5, 0.01, False,
+                                        dense_rows_possible=False)
+    loss1.backward()
+    f2, W2, b2, v2 = (t.clone().requires_grad_(True) for t in (feat, W, b, values))
+    loss2, st2 = O.ppo_loss(f2 @ W2.t() + b2, v2, bits, a1, lp1 - 0.1, adv, ret, None, 0.2, 0.5, 0.01, False)
+    loss2.backward()
+    assert torch.allclose(st1[:6], st2[:6], rtol=1e-4, atol=1e-6)
+    for x, y, name in ((f1, f2, "dfeat"), (W1, W2, "dW"), (b1, b2, "dbias"), (v1, v2, "dvalues")):
+        np.testing.assert_allclose(x.grad.cpu().numpy(), y.grad.cpu().numpy(), rtol=2e-4, atol=1e-7, err_msg=name)
+    # bit-reproducible: no float atomics anywhere in the backward
+    f3, W3, b3, v3 = (t.clone().requires_grad_(True) for t in (feat, W, b, values))
+    loss3, _ = O.policy_head_ppo_loss(f3, W3, b3, v3, bits, a1, lp1 - 0.1, adv, ret, None, 0.2, 0.5, 0.01, False,
+                                      dense_rows_possible=False)
+    loss3.backward()
+    assert torch.equal(W1.grad, W3.grad) and torch.equal(f1.grad, f3.grad) and torch.equal(b1.grad, b3.grad)
