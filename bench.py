@@ -55,6 +55,11 @@ def parse():
                          "(NOT the reference contract; the default run and the roofline replay keep float32 / byte masks)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the T-step self-play rollout from one captured hipGraph (BASELINE configs[4])")
+    ap.add_argument("--async-learner", action="store_true",
+                    help="BASELINE configs[4]: rollout i+1 on a second HIP stream (actor copy of the network, refreshed every "
+                         "--sync-interval iterations) while learn() consumes rollout i; changes the on-policy semantics, "
+                         "so it is not the default")
+    ap.add_argument("--sync-interval", type=int, default=1)
     ap.add_argument("--roofline-only", action="store_true", help="only time the env kernel (quick check)")
     return ap.parse_args()
 
@@ -154,6 +159,52 @@ def env_roofline(dev, n_games, replay_steps, seed):
             "fill_same_bytes_us": round(fill_us, 2)}
 
 
+def async_main(args, rank, world, dev, agent, env, buf, cfg, fmt, barrier, note):
+    """--async-learner: every timed step is one learner iteration with the NEXT rollout in flight on the side stream.
+    Reports the same whole-job metric; no roofline / cpu_baseline objects (the default run carries them)."""
+    from shogidrl_amd.async_learner import OverlappedSelfPlayLearner
+    from shogidrl_amd.buffer import VecExperienceBuffer
+    buf2 = VecExperienceBuffer(args.rollout, args.games, cfg.gamma, cfg.lambda_gae, dev, **fmt)
+    ov = OverlappedSelfPlayLearner(env, agent, [buf, buf2], sync_interval=args.sync_interval, graphed=args.graph)
+    for i in range(max(args.warmup, 3 if args.graph else 1)):     # (graphs: eager pass + capture for both buffers)
+        ov.step()
+        ov.synchronize()
+        note("warmup %d done" % i)
+    barrier()
+    t0 = time.perf_counter()
+    metrics = {}
+    for _ in range(args.steps):
+        metrics = ov.step()
+    ov.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.cpu()[0])
+    transitions = world * args.steps * args.rollout * args.games
+    if rank == 0:
+        print(json.dumps({
+            "metric": "env-steps/sec self-play + PPO samples/sec, 4096 games, 1/2/4/8 MI355X",
+            "value": transitions / elapsed, "unit": "env-steps/s", "n_gpus": world,
+            "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+            "backend": dist.get_backend() if dist.is_initialized() else "none (single rank)",
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4] schedule on configs[2] sizes: %d games per GPU, ResNet %dx%d+SE0.25, "
+                                   "rollout T=%d on a side stream (%s) overlapping PPO %d epochs x minibatch %d; actor weights "
+                                   "refreshed every %d iteration(s)" % (args.games, args.depth, args.width, args.rollout,
+                                                                        "hipGraph replay" if args.graph else "eager launches",
+                                                                        args.epochs, args.minibatch, args.sync_interval),
+                       "games_per_gpu": args.games, "rollout_len": args.rollout, "async_learner": True,
+                       "sync_interval": args.sync_interval, "parallelism": "dp%d" % world},
+            "rollout_weight_versions": ov.rollout_versions[-4:], "learner_version": ov.learner_version,
+            "ppo_metrics": metrics, "episodes": ov.episode_stats()}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -187,7 +238,7 @@ def main():
     fmt = dict(packed_masks=True, obs_format="bf16_nhwc") if args.compact else {}
     env = VecShogiEnv(args.games, 500, device=dev, **fmt)
     buf = VecExperienceBuffer(args.rollout, args.games, cfg.gamma, cfg.lambda_gae, dev, **fmt)
-    runner = SelfPlayRunner(env, agent, buf)
+    runner = None if args.async_learner else SelfPlayRunner(env, agent, buf)
 
     def barrier():
         torch.cuda.synchronize()
@@ -200,6 +251,8 @@ def main():
             print("[bench %7.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
     t_start = time.perf_counter()
+    if args.async_learner:
+        return async_main(args, rank, world, dev, agent, env, buf, cfg, fmt, barrier, note)
     collect = runner.collect
     if args.graph:
         runner.collect_graphed()                 # eager (allocations, MIOpen solver choice) ...

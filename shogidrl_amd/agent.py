@@ -66,31 +66,15 @@ def _gather_obs(obs, idx):
     return obs.index_select(0, idx)
 
 
-class VecPPOAgent:
-    def __init__(self, model, config=None, device="cuda:0", group=None, name="PPOAgent"):
-        self.config = config or PPOConfig()
-        self.device = torch.device(device)
-        self.name = name
-        self.model = model.to(self.device)
-        if self.config.channels_last:
-            self.model = self.model.to(memory_format=torch.channels_last)
-        self.group = group
-        self.policy_output_mapper = PolicyOutputMapper()
-        self.num_actions_total = self.policy_output_mapper.get_total_actions()
-        params = [p for p in self.model.parameters() if p.requires_grad]
-        self.bucket = FlatGradBucket(params, group)
-        kw = dict(lr=self.config.learning_rate, weight_decay=self.config.weight_decay)
-        try:
-            self.optimizer = torch.optim.Adam(params, fused=True, **kw)
-        except (RuntimeError, TypeError, ValueError):
-            self.optimizer = torch.optim.Adam(params, **kw)
+class _Acting:
+    """The acting half of the agent (select_actions / get_values over self.model); shared by VecPPOAgent and by the
+    weight-lagged ActingPolicy of the asynchronous learner."""
+
+    def _init_acting(self):
         self.fused_head = bool(self.config.fused_policy_head and hasattr(self.model, "policy_features")
                                and hasattr(self.model, "policy_linear"))
-        self._rng = np.random.default_rng(self.config.seed)       # minibatch shuffling (ppo_agent.py:100, 298)
         self._sample_step = 0
         self._step_tensor = None        # device-side twin of _sample_step while a captured rollout graph is in use
-        self.last_kl_div = 0.0
-        self.last_gradient_norm = 0.0
 
     # ------------------------------------------------------------------ acting
     def _forward(self, obs):
@@ -139,6 +123,57 @@ class VecPPOAgent:
         _, value = self._features(obs) if self.fused_head else self._forward(obs)   # no logits GEMM for a value
         return value
 
+
+class ActingPolicy(_Acting):
+    """A copy of the learner's network that only acts: the behaviour policy of the asynchronous learner's rollout
+    stream / actor ranks (the reference's SelfPlayWorker holds such a copy and refreshes it from the weights the trainer
+    pushes, keisei/training/parallel/self_play_worker.py:356-435).  `load_from` is that refresh, device to device."""
+
+    def __init__(self, model, config, device="cuda:0"):
+        import copy
+        self.config = config
+        self.device = torch.device(device)
+        self.model = copy.deepcopy(model).to(self.device)
+        for p in self.model.parameters():
+            p.requires_grad_(False)
+        self._init_acting()
+        self.weights_version = 0
+
+    @torch.no_grad()
+    def load_from(self, module, version=None):
+        """parameters AND buffers (BatchNorm running statistics) of `module`, one multi-tensor copy"""
+        src = [t.detach() for t in list(module.parameters()) + list(module.buffers())]
+        dst = [t.detach() for t in list(self.model.parameters()) + list(self.model.buffers())]
+        assert len(src) == len(dst)
+        torch._foreach_copy_(dst, src)
+        if version is not None:
+            self.weights_version = version
+
+
+class VecPPOAgent(_Acting):
+    def __init__(self, model, config=None, device="cuda:0", group=None, name="PPOAgent"):
+        self.config = config or PPOConfig()
+        self.device = torch.device(device)
+        self.name = name
+        self.model = model.to(self.device)
+        if self.config.channels_last:
+            self.model = self.model.to(memory_format=torch.channels_last)
+        self.group = group
+        self.policy_output_mapper = PolicyOutputMapper()
+        self.num_actions_total = self.policy_output_mapper.get_total_actions()
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        self.bucket = FlatGradBucket(params, group)
+        kw = dict(lr=self.config.learning_rate, weight_decay=self.config.weight_decay)
+        try:
+            self.optimizer = torch.optim.Adam(params, fused=True, **kw)
+        except (RuntimeError, TypeError, ValueError):
+            self.optimizer = torch.optim.Adam(params, **kw)
+        self._init_acting()
+        self._rng = np.random.default_rng(self.config.seed)       # minibatch shuffling (ppo_agent.py:100, 298)
+        self.last_kl_div = 0.0
+        self.last_gradient_norm = 0.0
+
+    # ------------------------------------------------------------------ single-game signatures of the reference
     def select_action(self, obs, legal_mask, *, is_training=True):
         """Single-game signature of the reference: (move tuple | None, index, log_prob, value)."""
         o = torch.as_tensor(obs, dtype=torch.float32, device=self.device).reshape(1, 46, 9, 9)

@@ -10,7 +10,9 @@ import torch
 
 
 class SelfPlayRunner:
-    def __init__(self, env, agent, buffer):
+    def __init__(self, env, agent, buffer, reset=True):
+        """reset=False: attach to an env that is already running (a second runner over another buffer of the same env --
+        the asynchronous learner's double buffering); call carry_from(other_buffer) before collecting."""
         assert env.num_games == buffer.N and env.packed_masks == buffer.packed_masks and env.emit_bits == buffer.emit_bits
         assert env.obs_format == getattr(buffer, "obs_format", "f32")
         self.env, self.agent, self.buffer = env, agent, buffer
@@ -19,10 +21,21 @@ class SelfPlayRunner:
         env.auto_reset = True
         # both mask forms per step (contract bytes + the bit-set the kernels read) unless one of them is switched off
         self._both = env.emit_bits and not env.packed_masks
+        if not reset:
+            return
         if self._both:
             env.reset(out_obs=buffer.obs[0], out_mask=buffer.legal_masks[0], out_bits=buffer.legal_bits[0])
         else:
             env.reset(out_obs=buffer.obs[0], out_mask=buffer.legal_masks[0])
+
+    def carry_from(self, other):
+        """continue the games where the rollout into `other` (a VecExperienceBuffer of the same shape) left them: its
+        bootstrap observation / masks become slot 0 of this runner's buffer"""
+        b, T = self.buffer, other.T
+        b.obs[0].copy_(other.obs[T])
+        b.legal_masks[0].copy_(other.legal_masks[T])
+        if b.legal_bits is not None and b.legal_bits is not b.legal_masks:
+            b.legal_bits[0].copy_(other.legal_bits[T])
 
     def collect_graphed(self):
         """collect() replayed from one hipGraph (BASELINE configs[4]: "hipGraph-captured rollout step").  Everything in
@@ -41,7 +54,8 @@ class SelfPlayRunner:
         if not getattr(self, "_graph_warm", False):
             self._graph_warm = True
             return self.collect()
-        agent._step_tensor = torch.tensor([agent._sample_step], dtype=torch.int64, device=self.env.device)
+        if agent._step_tensor is None:     # shared by every graph captured over this policy (two runners, two buffers)
+            agent._step_tensor = torch.tensor([agent._sample_step], dtype=torch.int64, device=self.env.device)
         side = torch.cuda.Stream(device=self.env.device)
         side.wait_stream(torch.cuda.current_stream())
         graph = torch.cuda.CUDAGraph()

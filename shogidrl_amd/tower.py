@@ -22,10 +22,17 @@ def _stream():
 
 
 def _workspace(device, C):
-    key = (device, C)
+    """Scratch for the batch-norm partial sums (statistics kernel -> finalize kernel).  It is reused by consecutive calls
+    on ONE stream; two streams (the asynchronous learner's rollout stream next to learn() on the main stream) must not
+    share it, so it is cached per stream.  While a hipGraph is being captured nothing is cached: the scratch then comes
+    from the graph's private pool and must not outlive the capture in a global."""
+    n = lib().ksh_tower_workspace_bytes(C) // 4
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(n, dtype=torch.float32, device=device)
+    key = (device, C, torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None:
-        ws = torch.empty(lib().ksh_tower_workspace_bytes(C) // 4, dtype=torch.float32, device=device)
+        ws = torch.empty(n, dtype=torch.float32, device=device)
         _workspaces[key] = ws
     return ws
 
