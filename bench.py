@@ -143,17 +143,25 @@ def env_roofline(dev, n_games, replay_steps, seed):
     fill_us = tm.elapsed_ms() / replay_steps * 1e3
     del scratch
     achieved = n_games * ENV_BYTES_PER_STEP / (ms * 1e-3) / 1e9
-    traffic = None
+    # HBM bytes per launch from the PMC passes (tools/env_traffic.py): only when they were taken on THIS kernel source
+    traffic, traffic_note = None, "no PMC measurement for this size"
     tfile = os.path.join(ROOT, "profiles", "env_kernel_hbm_traffic.json")
     if os.path.exists(tfile):
         try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from env_traffic import env_source_hash
             t = json.load(open(tfile))
-            if int(t.get("n_games", -1)) == n_games:
-                traffic = t.get("bytes_per_launch")
-        except (ValueError, OSError):
+            if int(t.get("n_games", -1)) != n_games:
+                traffic_note = "PMC file is for %s games" % t.get("n_games")
+            elif t.get("env_source_hash") != env_source_hash():
+                traffic_note = "stale: PMC passes were taken on another version of the env kernel (tools/env_traffic.py regenerates)"
+            else:
+                traffic, traffic_note = t.get("bytes_per_launch"), "rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes (profiles/env_kernel_hbm_traffic.json)"
+        except (ValueError, OSError, ImportError):
             traffic = None
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "ksh_env_step_kernel",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
+            "kernel": "ksh_env_step_kernel",
             "avg_launch_us": round(ms * 1e3, 2), "launches": replay_steps,
             "algorithmic_bytes_per_launch": n_games * ENV_BYTES_PER_STEP, "replay_deterministic": same,
             "fill_same_bytes_us": round(fill_us, 2)}

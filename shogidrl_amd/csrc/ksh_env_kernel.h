@@ -189,6 +189,16 @@ struct KshBlockLds {
     KshTables tab;
     KshWaveLds wave[KSH_WPB];
 };
+// Variant without the LDS copy of the attack tables (TABG = 1): the lookups go to global memory (24.9 KB that every CU's
+// vector L1 / the L2 keep hot), a block needs 8.8 KB of LDS instead of 33.6 KB and no barrier.  Measured, not assumed:
+// DESIGN.md section 4.1.
+struct KshBlockLdsG {
+    KshWaveLds wave[KSH_WPB];
+};
+template <int TABG> struct KshLdsSel { typedef KshBlockLds type; };
+template <> struct KshLdsSel<1> { typedef KshBlockLdsG type; };
+__device__ __forceinline__ const KshTables &ksh_tab_of(const KshBlockLds &L, const KshTables *) { return L.tab; }
+__device__ __forceinline__ const KshTables &ksh_tab_of(const KshBlockLdsG &, const KshTables *g) { return *g; }
 
 #define ST8(W) (reinterpret_cast<uint8_t *>((W).st32))
 
@@ -253,7 +263,7 @@ __device__ __forceinline__ uint32_t slice_word(Stream81 tn, Stream81 tp, int fro
 #else
 #define GEN_STAMP(k) do { } while (0)
 #endif
-__device__ __forceinline__ int ksh_gen(KshBlockLds &L, KshWaveLds &W, int lane, int me, bool emit, bool want_ufz,
+__device__ __forceinline__ int ksh_gen(const KshTables &TB, KshWaveLds &W, int lane, int me, bool emit, bool want_ufz,
                                        bool &in_check, BB3 &ufz_cand, unsigned long long *dbg = nullptr) {
     const uint8_t *brd = ST8(W);
     const int p0 = brd[lane];
@@ -296,13 +306,13 @@ __device__ __forceinline__ int ksh_gen(KshBlockLds &L, KshWaveLds &W, int lane, 
     const int kind = has ? (int)((KIND >> (4 * type)) & 0xF) : 0;
     const BB3 O = foe ? occx : occ;
     BB3 att = bb_zero();
-    if (has && cls != 15) att = lds_bb(L.tab.step, cls, sq);
+    if (has && cls != 15) att = lds_bb(TB.step, cls, sq);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const bool act = kind >= 2 || (kind == 1 && i == 0);
         const int d = kind == 3 ? i : (kind == 2 ? 4 + i : color);  // lance: Black slides N (0), White S (1)
         if (act) {
-            BB3 M = lds_bb(L.tab.ray, d, sq);
+            BB3 M = lds_bb(TB.ray, d, sq);
             att = bb_or(att, ray_attack(M, bb_and(M, O), (d & 1) != 0));
         }
     }
@@ -338,9 +348,9 @@ __device__ __forceinline__ int ksh_gen(KshBlockLds &L, KshWaveLds &W, int lane, 
     if (mine && ksq >= 0 && sq != ksq) {
         const int d = sq_dir(ksq, sq);
         if (d >= 0) {
-            const BB3 between = bb_and(lds_bb(L.tab.ray, d, ksq), lds_bb(L.tab.ray, d ^ 1, sq));
+            const BB3 between = bb_and(lds_bb(TB.ray, d, ksq), lds_bb(TB.ray, d ^ 1, sq));
             if (!bb_any(bb_and(between, occ))) {
-                const int n2 = bb_nearest(bb_and(lds_bb(L.tab.ray, d, sq), occ), (d & 1) != 0);
+                const int n2 = bb_nearest(bb_and(lds_bb(TB.ray, d, sq), occ), (d & 1) != 0);
                 if (n2 >= 0) {
                     const int q2 = brd[n2];
                     if ((q2 >= 15) != (me == 1)) {
@@ -360,7 +370,7 @@ __device__ __forceinline__ int ksh_gen(KshBlockLds &L, KshWaveLds &W, int lane, 
     if (ncheck == 1) {
         const int d = sq_dir(ksq, csq);
         BB3 between = bb_zero();
-        if (d >= 0) between = bb_and(lds_bb(L.tab.ray, d, ksq), lds_bb(L.tab.ray, d ^ 1, csq));
+        if (d >= 0) between = bb_and(lds_bb(TB.ray, d, ksq), lds_bb(TB.ray, d ^ 1, csq));
         block = bb_or(between, bb_sq(csq));
         dropok = bb_and(dropok, between);
     } else if (ncheck >= 2) {
@@ -378,7 +388,7 @@ __device__ __forceinline__ int ksh_gen(KshBlockLds &L, KshWaveLds &W, int lane, 
             T = bb_andn(T, katt);
         } else {
             T = bb_and(T, block);
-            if (pinned) T = bb_and(T, lds_bb(L.tab.ray, pin_d, ksq));
+            if (pinned) T = bb_and(T, lds_bb(TB.ray, pin_d, ksq));
         }
         // promotion rules (shogi_rules_logic.py:382-421)
         const bool promotable = type <= 3 || type == 5 || type == 6;
@@ -452,11 +462,11 @@ __device__ __forceinline__ int ksh_gen(KshBlockLds &L, KshWaveLds &W, int lane, 
 // Legal moves of `me` including the uchi-fu-zume decision (shogi_rules_logic.py:275-359): for every
 // candidate square drop the pawn on the LDS board, generate the opponent's replies (nested pawn drops
 // skip their own test, :461-467) and keep the drop unless it gives check AND leaves no reply.
-__device__ __forceinline__ int ksh_gen_full(KshBlockLds &L, KshWaveLds &W, int lane, int me, bool &in_check,
+__device__ __forceinline__ int ksh_gen_full(const KshTables &TB, KshWaveLds &W, int lane, int me, bool &in_check,
                                             unsigned long long *dbg = nullptr) {
     uint8_t *st8 = ST8(W);
     BB3 cand;
-    int n = ksh_gen(L, W, lane, me, true, true, in_check, cand, dbg);
+    int n = ksh_gen(TB, W, lane, me, true, true, in_check, cand, dbg);
 #ifdef KSH_STAMPS
     if (lane == 0 && dbg) { dbg[10] = __builtin_amdgcn_s_memtime(); dbg[9] = bb_any(cand) ? 1 : 0; }
 #endif
@@ -467,7 +477,7 @@ __device__ __forceinline__ int ksh_gen_full(KshBlockLds &L, KshWaveLds &W, int l
         wave_lds_sync();
         bool gives_check;
         BB3 none;
-        const int replies = ksh_gen(L, W, lane, 1 - me, false, false, gives_check, none);
+        const int replies = ksh_gen(TB, W, lane, 1 - me, false, false, gives_check, none);
         if (lane == 0) st8[s] = 0;
         wave_lds_sync();
         if (!(gives_check && replies == 0)) {
@@ -642,9 +652,10 @@ __device__ __forceinline__ void ksh_write_obs16(KshWaveLds &W, const KshStepArgs
 // observation store must leave as early as possible -- everything it does not need (table staging, move
 // generation) comes after it; (2) on gfx9 loads and stores share one in-order vmcnt, so every global LOAD of
 // a wave (state, action, history, tables) is issued AND consumed before its first observation store.
-template <int OBS16>
+template <int OBS16, int TABG>
 __device__ __forceinline__ void ksh_env_step_body(const KshStepArgs &a) {
-    __shared__ KshBlockLds L;
+    __shared__ typename KshLdsSel<TABG>::type L;
+    const KshTables &T = ksh_tab_of(L, a.tables);
 #ifdef KSH_STAMPS
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -665,11 +676,13 @@ __device__ __forceinline__ void ksh_env_step_body(const KshStepArgs &a) {
     constexpr int NV = (int)(sizeof(KshTables) / 16);   // uint4 count: 6 full rounds of 256 threads + a remainder
     constexpr int NT = 64 * KSH_WPB;
     static_assert(NV >= 6 * NT && NV < 7 * NT, "staging below is written for 6 full rounds + a remainder");
-    const uint4 *tsrc = reinterpret_cast<const uint4 *>(a.tables) + threadIdx.x;
-    const uint4 t0 = tsrc[0], t1 = tsrc[NT], t2 = tsrc[2 * NT], t3 = tsrc[3 * NT], t4 = tsrc[4 * NT], t5 = tsrc[5 * NT];
-    uint4 t6 = {0u, 0u, 0u, 0u};
+    uint4 t0 = {0u, 0u, 0u, 0u}, t1 = t0, t2 = t0, t3 = t0, t4 = t0, t5 = t0, t6 = t0;
     const bool trem = (int)threadIdx.x < NV - 6 * NT;
-    if (trem) t6 = tsrc[6 * NT];
+    if constexpr (!TABG) {
+        const uint4 *tsrc = reinterpret_cast<const uint4 *>(a.tables) + threadIdx.x;
+        t0 = tsrc[0]; t1 = tsrc[NT]; t2 = tsrc[2 * NT]; t3 = tsrc[3 * NT]; t4 = tsrc[4 * NT]; t5 = tsrc[5 * NT];
+        if (trem) t6 = tsrc[6 * NT];
+    }
 
     int out_done = 0, out_reason = 0, out_winner = -1, n_out = 0;
     bool obs_written = false, need_gen = true, moved = false;
@@ -828,12 +841,12 @@ __device__ __forceinline__ void ksh_env_step_body(const KshStepArgs &a) {
     }
 
     // ---- attack tables into LDS (24.9 KB, shared by the block's waves); their loads were issued at the top
-    {
-        uint4 *tdst = reinterpret_cast<uint4 *>(&L.tab) + threadIdx.x;
+    if constexpr (!TABG) {
+        uint4 *tdst = reinterpret_cast<uint4 *>(const_cast<KshTables *>(&T)) + threadIdx.x;
         tdst[0] = t0; tdst[NT] = t1; tdst[2 * NT] = t2; tdst[3 * NT] = t3; tdst[4 * NT] = t4; tdst[5 * NT] = t5;
         if (trem) tdst[6 * NT] = t6;
+        __syncthreads();
     }
-    __syncthreads();
     if (!live) return;  // wave-uniform
     KSH_STAMP(2);  // tables staged
 
@@ -841,9 +854,9 @@ __device__ __forceinline__ void ksh_env_step_body(const KshStepArgs &a) {
         // ---- legal moves of the side now to move (+ nested uchi-fu-zume reply search)
         bool chk;
 #ifdef KSH_STAMPS
-        int n = ksh_gen_full(L, W, lane, me, chk, a.stamps ? a.stamps + (size_t)g * 32 + 16 : nullptr);
+        int n = ksh_gen_full(T, W, lane, me, chk, a.stamps ? a.stamps + (size_t)g * 32 + 16 : nullptr);
 #else
-        int n = ksh_gen_full(L, W, lane, me, chk);
+        int n = ksh_gen_full(T, W, lane, me, chk);
 #endif
         KSH_STAMP(6);  // movegen done
         need_gen = false;
@@ -862,7 +875,7 @@ __device__ __forceinline__ void ksh_env_step_body(const KshStepArgs &a) {
         }
         if (out_done) {
             if (a.auto_reset) {
-                if (lane < 32) W.st32[lane] = reinterpret_cast<const uint32_t *>(L.tab.init_state)[lane];
+                if (lane < 32) W.st32[lane] = reinterpret_cast<const uint32_t *>(T.init_state)[lane];
                 for (int i = lane; i < KSH_MASKW; i += 64) W.maskbits[i] = 0;
                 wave_lds_sync();
                 me = 0;
@@ -879,7 +892,7 @@ __device__ __forceinline__ void ksh_env_step_body(const KshStepArgs &a) {
 
     if (need_gen) {
         bool chk;
-        int n = ksh_gen_full(L, W, lane, me, chk);
+        int n = ksh_gen_full(T, W, lane, me, chk);
         n_out = n;
         if (a.mode == 3 && st8[S_OVER] != 0) {          // already marked finished: report the stored verdict
             out_done = 1;
@@ -969,5 +982,7 @@ __device__ __forceinline__ void ksh_env_step_body(const KshStepArgs &a) {
 }
 
 // Two entry points over one body: the reference contract (float32 planes, NCHW) and the compact observation format.
-extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(KshStepArgs a) { ksh_env_step_body<0>(a); }
-extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_c16_kernel(KshStepArgs a) { ksh_env_step_body<1>(a); }
+extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(KshStepArgs a) { ksh_env_step_body<0, 0>(a); }
+extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_c16_kernel(KshStepArgs a) { ksh_env_step_body<1, 0>(a); }
+// same step, attack tables read from global memory instead of an LDS copy (ksh_env_set_table_mode)
+extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_gt_kernel(KshStepArgs a) { ksh_env_step_body<0, 1>(a); }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -36,6 +37,7 @@ struct KshEnv {
     int max_moves;
     int hist_cap;
     int obs_format;  // KSH_OBS_F32_NCHW | KSH_OBS_BF16_NHWC
+    int table_mode;  // 0: attack tables staged into LDS by every block; 1: read from global memory (float32 obs format only)
     uint8_t *state;
     unsigned long long *hist;
     KshTables *tables;
@@ -44,7 +46,7 @@ struct KshEnv {
 extern "C" {
 
 const char *ksh_last_error(void) { return g_err.c_str(); }
-int ksh_version(void) { return 100; }
+int ksh_version(void) { return 200; }
 
 int ksh_env_create(int device, int n_games, int max_moves, void **handle) {
     if (!handle || n_games <= 0 || max_moves <= 0 || max_moves > 65534) return fail_arg("ksh_env_create: bad argument");
@@ -54,6 +56,15 @@ int ksh_env_create(int device, int n_games, int max_moves, void **handle) {
     e->n = n_games;
     e->max_moves = max_moves;
     e->hist_cap = max_moves + 1;
+    e->obs_format = KSH_OBS_F32_NCHW;
+    {   // diagnostic / A-B switch; the default was chosen by measurement
+        // measured (profiles/r02_env_tables_lds_vs_global.log): LDS copy wins at 4096 games (24.6 vs 26.6 us), ties at
+        // 8192 .. 32 768 (within 2-4 % either way), loses at 65 536 (387 vs 369 us) where 7 instead of 4 waves per SIMD hide more latency
+        const char *tm = getenv("KSH_ENV_TABLES");
+        e->table_mode = n_games >= 65536 ? 1 : 0;
+        if (tm != nullptr && strcmp(tm, "global") == 0) e->table_mode = 1;
+        if (tm != nullptr && strcmp(tm, "lds") == 0) e->table_mode = 0;
+    }
     e->state = nullptr;
     e->hist = nullptr;
     e->tables = nullptr;
@@ -139,6 +150,8 @@ static int launch_env(KshEnv *e, int mode, const int64_t *actions, const uint8_t
     const int blocks = (e->n + KSH_WPB - 1) / KSH_WPB;
     if (e->obs_format == KSH_OBS_BF16_NHWC)
         hipLaunchKernelGGL(ksh_env_step_c16_kernel, dim3(blocks), dim3(64 * KSH_WPB), 0, (hipStream_t)stream, a);
+    else if (e->table_mode == 1)
+        hipLaunchKernelGGL(ksh_env_step_gt_kernel, dim3(blocks), dim3(64 * KSH_WPB), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(ksh_env_step_kernel, dim3(blocks), dim3(64 * KSH_WPB), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
