@@ -103,6 +103,40 @@ def cpu_baseline(seconds):
                           "sample": "%d env steps in %.1f s on %d threads" % (nk, dk, share)}}
 
 
+def minibatch64_rate(agent, buf, dev, updates=64):
+    """PPO update rate at the REFERENCE's minibatch size (default_config.yaml:88 `minibatch_size: 64`), on a bounded
+    sample: `updates` optimizer updates of 64 samples each drawn from the rollout buffer (one epoch over 64 x updates
+    samples), timed with hipEvents after the headline measurement.  Reported next to the GPU-sized minibatch of the
+    headline number ("default-64 run also reported for parity")."""
+    from shogidrl_amd.buffer import VecExperienceBuffer
+    from shogidrl_amd.env import DeviceTimer
+    n = 64 * updates
+    small = VecExperienceBuffer(1, n, buf.gamma, buf.lambda_gae, dev)
+    flat = lambda x: x.reshape(-1, *x.shape[2:])[:n]
+    small.obs[0].copy_(flat(buf.obs[:buf.T]))
+    small.legal_masks[0].copy_(flat(buf.legal_masks[:buf.T]))
+    small.legal_bits[0].copy_(flat(buf.legal_bits[:buf.T]))
+    for name in ("actions", "rewards", "log_probs", "values", "dones", "advantages", "returns"):
+        getattr(small, name)[0].copy_(flat(getattr(buf, name)))
+    small._advantages_computed = True
+    saved = (agent.config.minibatch_size, agent.config.ppo_epochs)
+    agent.config.minibatch_size, agent.config.ppo_epochs = 64, 1
+    try:
+        agent.learn(small)                       # warm-up (MIOpen picks its kernels for batch 64)
+        tm = DeviceTimer()
+        torch.cuda.synchronize()
+        tm.start()
+        agent.learn(small)
+        tm.stop()
+        ms = tm.elapsed_ms()
+    finally:
+        agent.config.minibatch_size, agent.config.ppo_epochs = saved
+    return {"value": n / (ms * 1e-3), "unit": "PPO samples/s", "minibatch_size": 64, "updates": updates,
+            "ms_per_update": ms / updates,
+            "sample": "%d optimizer updates of 64 samples (one epoch over %d transitions of the rollout buffer), after the "
+                      "timed region" % (updates, n)}
+
+
 def env_roofline(dev, n_games, replay_steps, seed):
     """Average device time of ksh_env_step_kernel from `replay_steps` back-to-back launches between two
     hipEvents on the launch stream: a recorded self-play action stream is replayed on a second env."""
@@ -333,6 +367,7 @@ def main():
             "episodes": runner.episode_stats(),
         }
         if world == 1 and not args.no_cpu_baseline:
+            out["ppo_reference_minibatch64"] = minibatch64_rate(agent, buf, dev)
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     if world > 1:
         dist.barrier()

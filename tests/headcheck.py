@@ -26,9 +26,9 @@ def onehot_head(logits):
     return feat, W
 
 
-def check_head_loss_golden(ops):
+def check_head_loss_golden(ops, cases=None):
     z = np.load(ppocheck.os.path.join(ppocheck.G, "ppo_loss.npz"))
-    for ci in range(int(z["n_cases"])):
+    for ci in (range(int(z["n_cases"])) if cases is None else cases):
         c = ppocheck.load_loss_case(z, ci)
         clip, vf, ent, vclip = (float(x) for x in c["cfg"])
         feat, W = onehot_head(c["logits"])

@@ -27,8 +27,8 @@ def test_emu_deep_sequences_sennichite_far_back_and_inert_games():
 
 
 def test_emu_traces_fixture():
-    # 24 of the 48 golden games here (the GPU suite replays all of them through the C-ABI)
-    assert envcheck.check_traces(make_env, max_games=24) > 7000
+    # 16 of the 48 golden games here (the GPU suite replays all of them through the C-ABI)
+    assert envcheck.check_traces(make_env, max_games=16) > 4500
 
 
 def test_emu_traces_no_autoreset_terminal_obs():
