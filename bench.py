@@ -277,6 +277,8 @@ def main():
     cfg = PPOConfig(ppo_epochs=args.epochs, minibatch_size=args.minibatch, mixed_precision=True, channels_last=True,
                     seed=42 + rank)
     agent = VecPPOAgent(model, cfg, dev)
+    if world > 1:
+        parallel.broadcast_parameters(agent.model, src=0)     # identical seeds already give identical weights; make it certain
     fmt = dict(packed_masks=True, obs_format="bf16_nhwc") if args.compact else {}
     env = VecShogiEnv(args.games, 500, device=dev, **fmt)
     buf = VecExperienceBuffer(args.rollout, args.games, cfg.gamma, cfg.lambda_gae, dev, **fmt)

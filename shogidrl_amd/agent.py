@@ -40,11 +40,11 @@ class PPOConfig:
     # Which log-probs are "old" in the PPO ratio.
     #   False = the reference: the ones select_action produced while acting (ppo_agent.py:150 acts in BatchNorm TRAIN
     #           mode, so they are taken under the batch statistics of ONE rollout step), although learn() re-evaluates
-    #           the same samples under the statistics of shuffled cross-timestep minibatches.  Measured on the MI355X
-    #           (tests/test_gpu_agent.py::test_first_minibatch_ratio_before_any_update, ResNet 2x32, 256 games x 8 plies):
-    #           the two differ by up to 1.4 nats per sample before any optimizer step, i.e. most ratios start clipped.
-    #   True  = one extra no-grad pass at the start of learn() re-computes them under learn-time statistics (running
-    #           statistics untouched): ratio == 1 / KL == 0 up to minibatch-composition noise when learning starts.
+    #           the same samples under the statistics of shuffled cross-timestep minibatches.  Measured on the MI355X with
+    #           the learning rate at zero: KL 0.043 and 49 % of the ratios outside the clip range BEFORE any update at
+    #           the bench configuration (4096 games, ResNet 9x256; profiles/r02_old_logp_mismatch_lr0_*.log).
+    #   True  = one extra no-grad pass over shuffled minibatches at the start of learn() re-computes them under
+    #           learn-time statistics (running statistics untouched): KL 0.0000, clip fraction 0.000 in the same run.
     #   None  = automatic: True when the model has BatchNorm layers (a DELIBERATE deviation from the reference,
     #           DESIGN.md section 2), False otherwise (nothing to reconcile).
     recompute_old_log_probs: Optional[bool] = None
@@ -170,6 +170,7 @@ class VecPPOAgent(_Acting):
             self.optimizer = torch.optim.Adam(params, **kw)
         self._init_acting()
         self._rng = np.random.default_rng(self.config.seed)       # minibatch shuffling (ppo_agent.py:100, 298)
+        self._recompute_rng = np.random.default_rng(self.config.seed + 0x5EED)
         self.last_kl_div = 0.0
         self.last_gradient_norm = 0.0
 
@@ -196,17 +197,23 @@ class VecPPOAgent(_Acting):
         for m in bns:
             m.momentum = 0.0                                       # running = 1 * running + 0 * batch
         out = torch.empty(obs.shape[0], dtype=torch.float32, device=self.device)
+        # SHUFFLED minibatches, like the ones learn() will use: a chunk of consecutive rows of a [T,N] rollout is one
+        # timestep's N boards, i.e. exactly the batch the action was taken under -- re-evaluating it reproduces the stored
+        # log-prob bit for bit and reconciles nothing.  Own generator: the learn-time shuffling stream is not disturbed.
+        order = self._recompute_rng.permutation(obs.shape[0])
+        perm = torch.from_numpy(order).to(self.device)
         try:
             for start in range(0, obs.shape[0], self.config.minibatch_size):
-                sl = slice(start, start + self.config.minibatch_size)
-                idx = torch.arange(sl.start, min(sl.stop, obs.shape[0]), device=self.device)
+                idx = perm[start:start + self.config.minibatch_size]
+                m_, a_ = masks.index_select(0, idx), actions.index_select(0, idx)
                 if self.fused_head:
                     feat, _ = self._features(_gather_obs(obs, idx))
                     lin = self.model.policy_linear
-                    out[sl], _ = ops.policy_head_evaluate(feat, lin.weight, lin.bias, masks[sl], actions[sl], dense)
+                    lp, _ = ops.policy_head_evaluate(feat, lin.weight, lin.bias, m_, a_, dense)
                 else:
                     logits, _ = self._forward(_gather_obs(obs, idx))
-                    out[sl], _ = ops.evaluate_actions(logits, masks[sl], actions[sl])
+                    lp, _ = ops.evaluate_actions(logits, m_, a_)
+                out.index_copy_(0, idx, lp)
         finally:
             for m, (mom, nbt) in zip(bns, saved):
                 m.momentum = mom

@@ -15,9 +15,16 @@ from shogidrl_amd.models import ResTowerActorCritic
 from shogidrl_amd.rollout import SelfPlayRunner
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+# "reference": old log-probs as stored while acting (the reference's semantics); "recompute" (default for BatchNorm models):
+# re-computed under learn-time statistics at the start of learn() (deviation 6)
+mode = sys.argv[2] if len(sys.argv) > 2 else "recompute"
+epochs = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+lr = float(sys.argv[4]) if len(sys.argv) > 4 else 3e-4     # 0: the weights never move, so kl / clip_frac ARE the old-vs-new mismatch
 torch.backends.cudnn.benchmark = True
 torch.manual_seed(42)
-cfg = PPOConfig(ppo_epochs=10, minibatch_size=4096, mixed_precision=True, channels_last=True, seed=42)
+cfg = PPOConfig(ppo_epochs=epochs, minibatch_size=4096, mixed_precision=True, channels_last=True, seed=42,
+                recompute_old_log_probs=(mode != "reference"), learning_rate=lr)
+print("old log-probs: %s; ppo_epochs %d" % (mode, epochs), flush=True)
 agent = VecPPOAgent(ResTowerActorCritic(46, 13527, 9, 256, 0.25), cfg, "cuda:0")
 env = VecShogiEnv(4096, 500, device="cuda:0")
 buf = VecExperienceBuffer(32, 4096, cfg.gamma, cfg.lambda_gae, "cuda:0")
