@@ -527,6 +527,7 @@ static int head_loss_impl(const float *feat, const float *W, const float *bias, 
         d.SEGW = w.SEGW; d.NSEG = w.NSEG; d.n_items = w.n_items; d.items = w.items; d.table = w.table;
         d.partial = w.prow; d.partial_dz = w.pdz;
         d.light_max = 64;
+        if (const char *lm = getenv("KSH_HEAD_LIGHT_MAX")) d.light_max = atoi(lm);     // tuning switch (tools/headdiag.py)
         const dim3 ag((KSH_PA + KSH_DW_WPB - 1) / KSH_DW_WPB), ab(64 * KSH_DW_WPB);
         hipLaunchKernelGGL(ksh_head_dw_scan_kernel, dim3((KSH_PA + KSH_DW_SCAN_WPB - 1) / KSH_DW_SCAN_WPB),
                            dim3(64 * KSH_DW_SCAN_WPB), 0, st, d);
