@@ -402,3 +402,36 @@ def test_first_minibatch_ratio_before_any_update():
     assert all(np.isfinite(v) for v in out[False])
     assert abs(out[True][0]) < 2e-3 and out[True][1] < 0.01, out
     assert abs(out[True][0]) <= abs(out[False][0]) + 1e-6
+
+
+def test_fused_policy_head_and_logits_path_learn_the_same_update():
+    """VecPPOAgent with the fused policy head (features -> HIP kernels, no logits) against the same agent taking the logits
+    path (framework GEMM + ops.masked_sample / ops.ppo_loss): same rollout decisions, same update."""
+    from shogidrl_amd.agent import PPOConfig, VecPPOAgent
+    from shogidrl_amd.buffer import VecExperienceBuffer
+    from shogidrl_amd.env import VecShogiEnv
+    from shogidrl_amd.models import ResTowerActorCritic
+    from shogidrl_amd.rollout import SelfPlayRunner
+    N, T = 128, 6
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(0)
+        cfg = PPOConfig(ppo_epochs=2, minibatch_size=256, seed=9, fused_policy_head=fused, recompute_old_log_probs=False)
+        agent = VecPPOAgent(ResTowerActorCritic(46, A, 2, 32, 0.25), cfg, DEV)
+        assert agent.fused_head == fused
+        run = SelfPlayRunner(VecShogiEnv(N, 60, device=DEV), agent, VecExperienceBuffer(T, N, cfg.gamma, cfg.lambda_gae, DEV))
+        run.collect()
+        snap = dict(actions=run.buffer.actions.clone(), logp=run.buffer.log_probs.clone(), values=run.buffer.values.clone())
+        snap["metrics"] = run.update()
+        snap["params"] = torch.cat([p.detach().reshape(-1) for p in agent.model.parameters()]).clone()
+        res.append(snap)
+    a, b = res
+    same = a["actions"] == b["actions"]                       # float32 logit noise may flip a near-tie of the Gumbel keys
+    assert float(same.float().mean()) > 0.995
+    if bool(same.all()):
+        assert torch.allclose(a["logp"], b["logp"], atol=2e-5) and torch.allclose(a["values"], b["values"], atol=1e-6)
+        for k in ("ppo/policy_loss", "ppo/value_loss", "ppo/entropy", "ppo/kl_divergence_approx", "ppo/clip_fraction"):
+            assert abs(a["metrics"][k] - b["metrics"][k]) < 2e-4, k
+        # Adam moves every weight by about lr per update whatever the gradient's size: compare at that scale
+        assert float((a["params"] - b["params"]).abs().max()) < 4 * 3e-4 * 2
+        assert float((a["params"] - b["params"]).abs().mean()) < 1e-5

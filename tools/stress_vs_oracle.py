@@ -35,6 +35,7 @@ def run(n, steps, max_moves, drop_bias, seed):
         else:
             assert np.array_equal(env.obs.cpu().numpy(), o[0]), ("obs", k)
             assert np.array_equal(env.legal_mask.cpu().numpy().astype(np.uint8), o[1]), ("mask", k)
+            assert torch.equal(ops.unpack_mask(env.legal_bits), env.legal_mask), ("packed twin of the byte mask", k)
         assert np.array_equal(env.reward.cpu().numpy(), o[3]) and np.array_equal(env.done.cpu().numpy().astype(np.uint8), o[4]), ("done", k)
         assert np.array_equal(env.reason.cpu().numpy(), o[5]) and np.array_equal(env.winner.cpu().numpy(), o[6]), ("reason", k)
         for r in range(1, 6):
@@ -44,6 +45,7 @@ def run(n, steps, max_moves, drop_bias, seed):
                   (n, k + 1, time.time() - t0, stats[1], stats[2], stats[3], stats[4]), flush=True)
     return stats
 
+print("attack tables: %s" % os.environ.get("KSH_ENV_TABLES", "library default (LDS copy below 65 536 games)"), flush=True)
 tot = np.zeros(6, np.int64)
 for (n, steps, mm, db, seed) in [(768, 620, 500, 0.0, 1), (512, 400, 500, 0.6, 2), (512, 300, 90, 0.3, 3)]:
     print("run n=%d steps=%d max_moves=%d drop_bias=%.1f" % (n, steps, mm, db), flush=True)
