@@ -369,16 +369,11 @@ __global__ void __launch_bounds__(64 * KSH_HEAD_WPB) ksh_head_loss_kernel(KshHea
         z[e] = y * (G - c);
     }
     ksh_head_wave_sync();
-#ifndef KSH_DIAG_NO_DFEAT
     // dfeat[b] = sum_e dz_e W[list[e]]: lanes own the quads q = lane + 64 i of the row (one 16-byte load per entry and
     // lane for K = 162), U entries' loads in flight at once
     {
         constexpr int QQ = (KMAX / 4 + 63) / 64;
-#ifdef KSH_DIAG_U16
-        constexpr int U = QQ == 1 ? 16 : 2;
-#else
-        constexpr int U = QQ == 1 ? 8 : 2;
-#endif
+        constexpr int U = QQ == 1 ? 8 : 2;      // (16 in flight measured no faster: profiles/r02_head_kernels_pmc.txt)
         const int nq = a.K >> 2;
         const bool tail = (a.K & 2) != 0;
         float4 acc[QQ];
@@ -412,21 +407,12 @@ __global__ void __launch_bounds__(64 * KSH_HEAD_WPB) ksh_head_loss_kernel(KshHea
             if (q < nq) drow[2 * q + 1] = make_float2(acc[i].z, acc[i].w);
         }
     }
-#endif
     // transposed scatter for the weight gradient: dzT[a][b], bit b of bitsT row a
-#ifndef KSH_DIAG_NO_SCATTER
     for (int e = lane; e < n; e += 64) {
         const int j = (int)list[e];
-#ifdef KSH_DIAG_NT
-        __builtin_nontemporal_store(z[e], &a.dzT[(size_t)j * (size_t)a.B + (size_t)b]);
-#else
         a.dzT[(size_t)j * (size_t)a.B + (size_t)b] = z[e];
-#endif
-#ifndef KSH_DIAG_NO_ATOMIC
         atomicOr(&a.bitsT[(size_t)j * (size_t)a.BW + (size_t)(b >> 5)], 1u << (b & 31));
-#endif
     }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------ weight gradient
