@@ -495,7 +495,7 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_DW_SCAN_WPB) ksh_head_dw_s
 template <int KMAX>
 __global__ void __launch_bounds__(64 * KSH_DW_WPB) ksh_head_dw_work_kernel(KshHeadDwArgs a) {
     constexpr int QQ = (KMAX / 4 + 63) / 64;
-    constexpr int T = QQ == 1 ? 8 : 2;
+    constexpr int T = QQ == 1 ? 8 : 2;      // (4 / 16 in flight measure the same, 32 slower: profiles/r02_head_kernels_pmc.txt)
     __shared__ int s_rows[KSH_DW_WPB][KSH_DW_WIN];
     __shared__ float s_dz[KSH_DW_WPB][KSH_DW_WIN];
     const int lane = threadIdx.x & 63;
