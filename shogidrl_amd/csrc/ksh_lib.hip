@@ -385,7 +385,7 @@ static int loss_impl(const void *logits, int logits_dtype, const uint8_t *mask, 
 }
 
 // ---------------------------------------------------------------------------------- fused policy head
-// workspace layout: partial [B][8] floats | 16 words (0: dense-row counter, 1: work-list length) | bitsT [A][BW] | dzT [A][B]
+// workspace layout: partial [B][8] floats | 256 B (word 0: dense-row counter, word 1: work-list length) | bitsT [A][BW] | dzT [A][B]
 //                   | items [A*NSEG] | table [A][2] | partial rows [A*NSEG][K] | partial dz [A*NSEG]
 //                   | (dense) logits scratch [B][A] | (dense) dlogits scratch [B][A]
 struct HeadWs {
@@ -405,9 +405,10 @@ static HeadWs head_ws(void *workspace, int B, int K, int dense) {
     HeadWs w;
     char *p = (char *)workspace;
     w.partial = (float *)p;
-    w.n_over = (unsigned *)(p + (size_t)B * 32);
-    w.n_items = w.n_over + 1;
     p += head_align((size_t)B * 32 + 64);
+    w.n_over = (unsigned *)p;                 // the two counters sit right in front of the bit matrix: ONE memset zeroes all three
+    w.n_items = w.n_over + 1;
+    p += 256;
     w.BW = (B + 31) / 32;
     const int maxseg = K <= 192 ? 16 : 4;                 // partial-row scratch is [A * NSEG][K]
     w.SEGW = (w.BW + maxseg - 1) / maxseg;
@@ -499,8 +500,7 @@ static int head_loss_impl(const float *feat, const float *W, const float *bias, 
     a.want_grad = want_grad;
     a.dfeat = dfeat; a.dzT = w.dzT; a.bitsT = w.bitsT; a.BW = w.BW; a.n_over = w.n_over;
     // the dense-row counter and (for the backward) the transposed bit matrix start from zero
-    HIP_TRY(hipMemsetAsync(w.n_over, 0, 64, st));
-    if (want_grad) HIP_TRY(hipMemsetAsync(w.bitsT, 0, (size_t)KSH_PA * w.BW * 4, st));
+    HIP_TRY(hipMemsetAsync(w.n_over, 0, want_grad ? 256 + (size_t)KSH_PA * w.BW * 4 : 256, st));
     const dim3 grid((B + KSH_HEAD_WPB - 1) / KSH_HEAD_WPB), block(64 * KSH_HEAD_WPB);
     if (K <= 192) hipLaunchKernelGGL(ksh_head_loss_kernel<192>, grid, block, 0, st, a);
     else hipLaunchKernelGGL(ksh_head_loss_kernel<1312>, grid, block, 0, st, a);
