@@ -662,6 +662,11 @@ struct KshGemmArgs {
     const unsigned *n_over;
     int mode;
     float *C2;                // mode 2: dbias
+    // split-K (mode 1 only: dfeat = dl W has a 13 527-long reduction but only B x K outputs, i.e. a few dozen tiles):
+    // blockIdx.z takes the reduction steps [z * kchunk, (z + 1) * kchunk) and writes its partial tile to
+    // Cpart[z][M][N]; ksh_head_splitk_reduce_kernel adds the slices in order.  ksplit <= 1: no split.
+    int ksplit, kchunk;
+    float *Cpart;
 };
 
 #define KSH_GEMM_BM 64
@@ -687,7 +692,10 @@ extern "C" __global__ void __launch_bounds__(256) ksh_head_gemm_kernel(KshGemmAr
     for (int r = 0; r < 16; r++) acc[r] = 0.0f;
     const bool a_kfast = g.sAk == 1, b_kfast = g.sBk == 1;
     bool contributed = false;
-    for (int k0 = 0; k0 < g.Kd; k0 += KSH_GEMM_BK) {
+    const bool split = g.ksplit > 1;
+    const int kbeg = split ? (int)blockIdx.z * g.kchunk : 0;
+    const int kend = split ? ((kbeg + g.kchunk < g.Kd) ? kbeg + g.kchunk : g.Kd) : g.Kd;
+    for (int k0 = kbeg; k0 < kend; k0 += KSH_GEMM_BK) {
         if (g.mode == 2) {                                 // the reduction runs over sample rows: skip steps without a dense one
             __syncthreads();
             if (t == 0) s_any = 0;
@@ -705,13 +713,13 @@ extern "C" __global__ void __launch_bounds__(256) ksh_head_gemm_kernel(KshGemmAr
             if (a_kfast) { kk = t & 15; i = (t >> 4) + 16 * q; } else { i = t & 63; kk = (t >> 6) + 4 * q; }
             const int m = m0 + i, k = k0 + kk;
             float v = 0.0f;
-            if (m < g.M && k < g.Kd && (g.mode != 2 || g.flags[(size_t)k * 8] != 0.0f)) v = g.A[(long long)m * g.sAm + (long long)k * g.sAk];
+            if (m < g.M && k < kend && (g.mode != 2 || g.flags[(size_t)k * 8] != 0.0f)) v = g.A[(long long)m * g.sAm + (long long)k * g.sAk];
             As[kk][i] = v;
             if (b_kfast) { kk = t & 15; i = (t >> 4) + 16 * q; } else { i = t & 63; kk = (t >> 6) + 4 * q; }
             const int n = n0 + i;
             const int kb = k0 + kk;
             v = 0.0f;
-            if (n < g.N && kb < g.Kd) v = (g.mode == 2 && n == g.N - 1) ? 1.0f : g.Bm[(long long)kb * g.sBk + (long long)n * g.sBn];
+            if (n < g.N && kb < kend) v = (g.mode == 2 && n == g.N - 1) ? 1.0f : g.Bm[(long long)kb * g.sBk + (long long)n * g.sBn];
             Bs[kk][i] = v;
         }
         __syncthreads();
@@ -728,11 +736,27 @@ extern "C" __global__ void __launch_bounds__(256) ksh_head_gemm_kernel(KshGemmAr
         const int m = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int n = n0 + 32 * wn + (lane & 31);
         if (m >= g.M || n >= g.N) continue;
+        if (split) {            // partial tile of this reduction slice (every row of a tile that holds a flagged row)
+            g.Cpart[((size_t)blockIdx.z * (size_t)g.M + (size_t)m) * (size_t)g.N + (size_t)n] = acc[r];
+            continue;
+        }
         if (g.mode == 2) {
             if (n == g.N - 1) { if (g.C2 != nullptr) g.C2[m] += acc[r]; }
             else g.C[(long long)m * g.sCm + n] += acc[r];
         } else if (g.flags[(size_t)m * 8] != 0.0f) {
             g.C[(long long)m * g.sCm + n] = acc[r] + (g.bias != nullptr ? g.bias[n] : 0.0f);
         }
+    }
+}
+
+// C[m][n] = sum over the ksplit slices (ascending) of Cpart[z][m][n], for the flagged rows only.
+extern "C" __global__ void __launch_bounds__(256) ksh_head_splitk_reduce_kernel(KshGemmArgs g) {
+    if (*g.n_over == 0u) return;
+    const int m = (int)blockIdx.x;
+    if (g.flags[(size_t)m * 8] == 0.0f) return;           // block-uniform
+    for (int n = (int)threadIdx.x; n < g.N; n += (int)blockDim.x) {
+        float v = 0.0f;
+        for (int z = 0; z < g.ksplit; z++) v += g.Cpart[((size_t)z * (size_t)g.M + (size_t)m) * (size_t)g.N + (size_t)n];
+        g.C[(long long)m * g.sCm + n] = v;
     }
 }

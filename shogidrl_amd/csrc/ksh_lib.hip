@@ -396,10 +396,11 @@ struct HeadWs {
     uint32_t *items;
     int *table;
     float *prow, *pdz;
-    float *zbuf, *dlbuf;
+    float *zbuf, *dlbuf, *cpart;
     int BW, SEGW, NSEG;
     size_t bytes;
 };
+#define KSH_HEAD_KSPLIT 32
 static size_t head_align(size_t x) { return (x + 255) & ~(size_t)255; }
 static HeadWs head_ws(void *workspace, int B, int K, int dense) {
     HeadWs w;
@@ -425,12 +426,14 @@ static HeadWs head_ws(void *workspace, int B, int K, int dense) {
     p += head_align((size_t)KSH_PA * w.NSEG * K * 4);
     w.pdz = (float *)p;
     p += head_align((size_t)KSH_PA * w.NSEG * 4);
-    w.zbuf = w.dlbuf = nullptr;
+    w.zbuf = w.dlbuf = w.cpart = nullptr;
     if (dense) {
         w.zbuf = (float *)p;
         p += head_align((size_t)KSH_PA * B * 4);
         w.dlbuf = (float *)p;
         p += head_align((size_t)KSH_PA * B * 4);
+        w.cpart = (float *)p;                              // split-K partial tiles of the dense dfeat product
+        p += head_align((size_t)KSH_HEAD_KSPLIT * B * K * 4);
     }
     w.bytes = (size_t)(p - (char *)workspace);
     return w;
@@ -546,7 +549,13 @@ static int head_loss_impl(const float *feat, const float *W, const float *bias, 
             g.Bm = W; g.sBk = K; g.sBn = 1;
             g.C = dfeat; g.sCm = K;
             g.M = B; g.N = K; g.Kd = KSH_PA; g.bias = nullptr;
-            hipLaunchKernelGGL(ksh_head_gemm_kernel, dim3((B + 63) / 64, (K + 63) / 64), gb, 0, st, g);
+            // 13 527 reduction steps for a handful of output tiles: split the reduction 32 ways, add the slices in order
+            g.ksplit = KSH_HEAD_KSPLIT;
+            g.kchunk = ((KSH_PA + KSH_HEAD_KSPLIT - 1) / KSH_HEAD_KSPLIT + KSH_GEMM_BK - 1) / KSH_GEMM_BK * KSH_GEMM_BK;
+            g.Cpart = w.cpart;
+            hipLaunchKernelGGL(ksh_head_gemm_kernel, dim3((B + 63) / 64, (K + 63) / 64, KSH_HEAD_KSPLIT), gb, 0, st, g);
+            hipLaunchKernelGGL(ksh_head_splitk_reduce_kernel, dim3(B), gb, 0, st, g);
+            g.ksplit = 0; g.kchunk = 0; g.Cpart = nullptr;
             g.mode = 2;
             g.A = w.dlbuf; g.sAm = 1; g.sAk = KSH_PA;
             g.Bm = feat; g.sBk = K; g.sBn = 1;

@@ -29,7 +29,7 @@ static void die(const char *msg, int wave) {
     abort();
 }
 
-void run_block(void (*entry)(void *), void *arg, int block_idx, int nthreads, int block_idy) {
+void run_block(void (*entry)(void *), void *arg, int block_idx, int nthreads, int block_idy, int block_idz) {
     static Block blk;
     static Lane *lanes = nullptr;
     static int cap = 0;
@@ -41,7 +41,7 @@ void run_block(void (*entry)(void *), void *arg, int block_idx, int nthreads, in
     B = &blk;
     blk.nthreads = nthreads;
     blk.lanes = lanes;
-    blk.bidx = EmuDim3{block_idx, block_idy, 0};
+    blk.bidx = EmuDim3{block_idx, block_idy, block_idz};
     blk.bdim = EmuDim3{nthreads, 1, 1};
     blk.entry = entry;
     blk.entry_arg = arg;

@@ -52,7 +52,7 @@ struct Block {
 extern Block *B;
 inline Lane &me() { return B->lanes[B->cur]; }
 uint64_t park(int op, uint64_t arg, int arg2);
-void run_block(void (*entry)(void *), void *arg, int block_idx, int nthreads, int block_idy = 0);
+void run_block(void (*entry)(void *), void *arg, int block_idx, int nthreads, int block_idy = 0, int block_idz = 0);
 inline EmuDim3 tid() { return EmuDim3{B->lanes[B->cur].tid, 0, 0}; }
 inline EmuDim3 bid() { return B->bidx; }
 inline EmuDim3 bdim() { return B->bdim; }
