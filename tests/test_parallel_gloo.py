@@ -130,6 +130,27 @@ def _bn_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_four_ranks_keep_identical_state_dicts():
+    """the same worker at world_size 4 (the N = 4 point of the scaling run): every rank ends with the same state dict,
+    running statistics = the mean over the four ranks, and the batch-size check raises everywhere"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bn_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res = [tuple(torch.from_numpy(x) if hasattr(x, "dtype") else x for x in r) for r in res]
+    states = [r[6] for r in res]
+    assert all(torch.equal(states[0], s) for s in states[1:])
+    mean_before = sum(r[1] for r in res) / 4
+    assert torch.allclose(res[0][3], mean_before, atol=1e-6)
+    assert all(r[7] for r in res) and all(r[5] == 3 for r in res)
+
+
 def test_two_rank_batchnorm_buffers_are_synchronised_and_unequal_batches_fail_loudly():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
