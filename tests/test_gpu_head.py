@@ -139,3 +139,67 @@ def test_gpu_fused_head_agrees_with_logits_kernels_on_self_play_masks(N):
                                       dense_rows_possible=False)
     loss3.backward()
     assert torch.equal(W1.grad, W3.grad) and torch.equal(f1.grad, f3.grad) and torch.equal(b1.grad, b3.grad)
+
+
+@pytest.mark.parametrize("B,K", [(1, 2), (3, 6), (33, 162), (64, 164), (65, 160), (257, 162), (300, 1312), (1025, 30), (5000, 162)])
+def test_gpu_fused_head_shape_sweep_against_the_logits_kernels(B, K):
+    """edge shapes: K with and without the trailing pair (K % 4 == 2), K = 2, the largest K, batches that are not a
+    multiple of 32 / 64 / 256 (ragged last dword, last segment, last window of the transposed bit matrix), B = 1 and a
+    batch larger than 4096 (more than 8 dwords per segment).  Reference = the logits-based HIP kernels on feat @ W.T + b
+    computed in float64 and rounded once."""
+    from shogidrl_amd import ops as O
+    g = torch.Generator(device="cuda:0").manual_seed(B * 7919 + K)
+    dev = "cuda:0"
+    feat = torch.randn(B, K, device=dev, generator=g)
+    W = torch.randn(A, K, device=dev, generator=g) * (1.5 / K ** 0.5)
+    b = torch.randn(A, device=dev, generator=g) * 0.3
+    # masks: 1 .. 120 legal actions per row, clustered like real move lists (runs of consecutive ids), a few shared hot actions
+    mask = torch.zeros(B, A, dtype=torch.bool, device=dev)
+    starts = torch.randint(0, A - 40, (B, 6), device=dev, generator=g)
+    lens = torch.randint(1, 21, (B, 6), device=dev, generator=g)
+    ar = torch.arange(A, device=dev)
+    for c in range(6):
+        mask |= (ar[None, :] >= starts[:, c:c + 1]) & (ar[None, :] < (starts[:, c:c + 1] + lens[:, c:c + 1]))
+    mask[:, 4242] = True                                   # legal everywhere: the heavy-action path whenever B > 64
+    mask[::3, 13526] = True                                # the last action id
+    logits = (feat.double() @ W.double().t() + b.double()).float()
+    values = torch.randn(B, device=dev, generator=g)
+    adv, ret = torch.randn(B, device=dev, generator=g), torch.randn(B, device=dev, generator=g)
+    a1, lp1 = O.policy_head_sample(feat, W, b, mask, 5, 2)
+    a2, lp2 = O.masked_sample(logits, mask, 5, 2)
+    same = a1 == a2
+    assert float(same.float().mean()) >= 0.99 and bool(mask.gather(1, a1[:, None]).all())
+    assert torch.allclose(lp1[same], lp2[same], atol=2e-5)
+    e1, h1 = O.policy_head_evaluate(feat, W, b, mask, a2)
+    e2, h2 = O.evaluate_actions(logits, mask, a2)
+    assert torch.allclose(e1, e2, atol=2e-5) and torch.allclose(h1, h2, atol=1e-4, rtol=1e-4)
+    stats, dfeat, dW, dbias, dval = O.policy_head_loss_grads(feat, W, b, values, mask, a2, lp2 - 0.05, adv, ret, None, 0.2, 0.5,
+                                                             0.01, False, dense_rows_possible=False)
+    lg = logits.clone().requires_grad_(True)
+    v2 = values.clone().requires_grad_(True)
+    loss2, st2 = O.ppo_loss(lg, v2, mask, a2, lp2 - 0.05, adv, ret, None, 0.2, 0.5, 0.01, False)
+    loss2.backward()
+    dl = lg.grad.double()
+    assert torch.allclose(stats[:6], st2[:6], rtol=2e-4, atol=2e-6)
+    scale = lambda t: float(t.abs().max()) + 1e-12
+    for got, want, name in ((dfeat, dl @ W.double(), "dfeat"), (dW, dl.t() @ feat.double(), "dW"), (dbias, dl.sum(0), "dbias"),
+                            (dval, v2.grad.double(), "dvalues")):
+        err = float((got.double() - want).abs().max())
+        assert err <= 3e-4 * scale(want) + 1e-7, (name, err, scale(want))
+    assert bool((dW[~mask.any(0)] == 0).all())
+
+
+def test_fused_head_rejects_unsupported_shapes():
+    from shogidrl_amd import ops as O
+    from shogidrl_amd._lib import KeiseiHipError
+    dev = "cuda:0"
+    mask = torch.zeros(2, A, dtype=torch.bool, device=dev)
+    mask[:, 5] = True
+    with pytest.raises(ValueError):
+        O.policy_head_sample(torch.zeros(2, 163, device=dev), torch.zeros(A, 163, device=dev), None, mask, 1, 0)      # odd K
+    with pytest.raises(ValueError):
+        O.policy_head_sample(torch.zeros(2, 1314, device=dev), torch.zeros(A, 1314, device=dev), None, mask, 1, 0)    # K too large
+    with pytest.raises(TypeError):
+        O.policy_head_sample(torch.zeros(2, 162, device=dev).half(), torch.zeros(A, 162, device=dev), None, mask, 1, 0)
+    with pytest.raises(KeiseiHipError):
+        O.policy_head_sample(torch.zeros(2, 162), torch.zeros(A, 162), None, mask.cpu(), 1, 0)                         # CPU tensors: no CPU path
