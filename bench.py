@@ -131,10 +131,29 @@ def minibatch64_rate(agent, buf, dev, updates=64):
         ms = tm.elapsed_ms()
     finally:
         agent.config.minibatch_size, agent.config.ppo_epochs = saved
-    return {"value": n / (ms * 1e-3), "unit": "PPO samples/s", "minibatch_size": 64, "updates": updates,
-            "ms_per_update": ms / updates,
-            "sample": "%d optimizer updates of 64 samples (one epoch over %d transitions of the rollout buffer), after the "
-                      "timed region" % (updates, n)}
+    out = {"value": n / (ms * 1e-3), "unit": "PPO samples/s", "minibatch_size": 64, "updates": updates,
+           "ms_per_update": ms / updates,
+           "sample": "%d optimizer updates of 64 samples (one epoch over %d transitions of the rollout buffer), after the "
+                     "timed region" % (updates, n)}
+    # the same updates replayed from one captured hipGraph (PPOConfig.graph_minibatch_step): at this size the loop is
+    # launch-bound, which is what graphs are for
+    try:
+        import copy
+        import dataclasses
+        from shogidrl_amd.agent import VecPPOAgent
+        gcfg = dataclasses.replace(agent.config, minibatch_size=64, ppo_epochs=1, graph_minibatch_step=True)
+        ga = VecPPOAgent(copy.deepcopy(agent.model), gcfg, dev)
+        ga.learn(small)                          # eager warm-up updates + capture
+        torch.cuda.synchronize()
+        tm.start()
+        ga.learn(small)
+        tm.stop()
+        gms = tm.elapsed_ms()
+        out["hipgraph_replay"] = {"value": n / (gms * 1e-3), "ms_per_update": gms / updates}
+        del ga
+    except Exception as e:                       # a side figure: never let it take the headline measurement down
+        out["hipgraph_replay"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
 
 
 def env_roofline(dev, n_games, replay_steps, seed):

@@ -53,6 +53,12 @@ class PPOConfig:
     # loss kernels and the [B,13527] logits and their gradient are never materialised.  False: logits through the
     # framework's GEMM, then ops.masked_sample / ops.ppo_loss.
     fused_policy_head: bool = True
+    # True: the optimizer update of one minibatch (gather -> tower forward -> fused head -> tower backward -> clip -> Adam)
+    # is captured ONCE per minibatch shape in a hipGraph and replayed for every later minibatch of that shape.  It pays
+    # where the loop is launch-bound -- the reference's default minibatch_size of 64 (default_config.yaml:88): some 600
+    # launches of a few microseconds each per update -- and changes nothing at GPU-sized minibatches.  Single rank, fused
+    # policy head and a minibatch that divides the batch only; anything else takes the eager loop.
+    graph_minibatch_step: bool = False
     mixed_precision: bool = False          # bf16 autocast of the tower (the reference uses fp16 + GradScaler)
     channels_last: bool = False
     seed: int = 42
@@ -164,10 +170,14 @@ class VecPPOAgent(_Acting):
         params = [p for p in self.model.parameters() if p.requires_grad]
         self.bucket = FlatGradBucket(params, group)
         kw = dict(lr=self.config.learning_rate, weight_decay=self.config.weight_decay)
+        if self.config.graph_minibatch_step:
+            kw["capturable"] = True                            # step counters live on the device (hipGraph replay)
         try:
             self.optimizer = torch.optim.Adam(params, fused=True, **kw)
         except (RuntimeError, TypeError, ValueError):
             self.optimizer = torch.optim.Adam(params, **kw)
+        self._step_graphs = {}                                 # (minibatch rows, batch signature) -> captured update
+        self._learn_id = 0
         self._init_acting()
         self._rng = np.random.default_rng(self.config.seed)       # minibatch shuffling (ppo_agent.py:100, 298)
         self._recompute_rng = np.random.default_rng(self.config.seed + 0x5EED)
@@ -248,6 +258,10 @@ class VecPPOAgent(_Acting):
         num = obs.shape[0]
         check_equal_batches(num, self.device, self.group)          # same minibatch count (= collectives) on every rank
         indices = np.arange(num)
+        self._learn_id += 1
+        graphed = bool(cfg.graph_minibatch_step and self.fused_head and num % cfg.minibatch_size == 0
+                       and not (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                and torch.distributed.get_world_size(self.group) > 1))
         acc = torch.zeros(8, dtype=torch.float32, device=self.device)
         gnorm = torch.zeros((), dtype=torch.float32, device=self.device)
         updates = 0
@@ -256,6 +270,10 @@ class VecPPOAgent(_Acting):
             perm = torch.from_numpy(indices.copy()).to(self.device)   # a copy: `indices` is reshuffled in place next epoch
             for start in range(0, num, cfg.minibatch_size):
                 idx = perm[start:start + cfg.minibatch_size]
+                if graphed:
+                    gnorm = self._graphed_update(idx, obs, masks, actions, old_logp, adv, ret, old_values, dense, acc)
+                    updates += 1
+                    continue
                 rest = (masks.index_select(0, idx), actions.index_select(0, idx), old_logp.index_select(0, idx),
                         adv.index_select(0, idx), ret.index_select(0, idx), old_values.index_select(0, idx),
                         cfg.clip_epsilon, cfg.value_loss_coeff, cfg.entropy_coef, cfg.enable_value_clipping)
@@ -295,6 +313,71 @@ class VecPPOAgent(_Acting):
         return {"ppo/policy_loss": float(acc[1]), "ppo/value_loss": float(acc[2]), "ppo/entropy": float(acc[3]),
                 "ppo/kl_divergence_approx": float(acc[4]), "ppo/clip_fraction": float(acc[5]),
                 "ppo/learning_rate": self.optimizer.param_groups[0]["lr"]}
+
+    # ------------------------------------------------------------------ hipGraph-captured minibatch update
+    def _update_from(self, idx, obs, masks, actions, old_logp, adv, ret, old_values, dense, acc):
+        """one optimizer update on the rows `idx` (fused policy head, single rank): the body the graph captures"""
+        cfg = self.config
+        rest = (masks.index_select(0, idx), actions.index_select(0, idx), old_logp.index_select(0, idx),
+                adv.index_select(0, idx), ret.index_select(0, idx), old_values.index_select(0, idx),
+                cfg.clip_epsilon, cfg.value_loss_coeff, cfg.entropy_coef, cfg.enable_value_clipping)
+        self.bucket.begin()
+        feat, values = self._features(_gather_obs(obs, idx))
+        lin = self.model.policy_linear
+        gw = self.bucket.view_of(lin.weight)
+        gb = self.bucket.view_of(lin.bias) if lin.bias is not None else None
+        stats, dfeat, dW, dbias, dvalues = ops.policy_head_loss_grads(
+            feat.detach(), lin.weight.detach(), None if lin.bias is None else lin.bias.detach(), values.detach(), *rest,
+            dense_rows_possible=dense, out_dweight=gw, out_dbias=gb)
+        torch.autograd.backward([feat, values], [dfeat, dvalues.to(values.dtype)])
+        lin.weight.grad = dW
+        if lin.bias is not None:
+            lin.bias.grad = dbias
+        self.bucket.gather()
+        flat = self.bucket.flat
+        gnorm = torch.linalg.vector_norm(flat)
+        flat.mul_(torch.clamp(cfg.gradient_clip_max_norm / (gnorm + 1e-6), max=1.0))
+        self.optimizer.step()
+        acc += stats
+        return gnorm
+
+    def _graphed_update(self, idx, obs, masks, actions, old_logp, adv, ret, old_values, dense, acc):
+        """Replay (capturing it on first use) the hipGraph of one minibatch update.  The graph reads the minibatch's row
+        indices, the per-sample vectors that change between learn() calls (old log-probs, advantages) and the metric
+        accumulator from STATIC tensors that are refreshed by copies (returns too: the GAE op hands out new tensors); the
+        big buffers (observations, masks, actions, values) are captured by address, which is valid as long as learn() is handed the same buffer."""
+        key = (int(idx.numel()), obs.data_ptr(), masks.data_ptr(), actions.data_ptr(), old_values.data_ptr(), tuple(obs.shape),
+               bool(dense))
+        g = self._step_graphs.get(key)
+        if g is None:
+            st = {"idx": idx.clone(), "old_logp": old_logp.clone(), "adv": adv.clone(), "ret": ret.clone(),
+                  "acc": torch.zeros_like(acc), "warm": 0, "graph": None, "gnorm": None}
+            self._step_graphs[key] = g = st
+        g["idx"].copy_(idx)
+        if g.get("learn_id") != self._learn_id:             # once per learn(): this call's old log-probs / advantages
+            g["learn_id"] = self._learn_id
+            g["old_logp"].copy_(old_logp)
+            g["adv"].copy_(adv)
+            g["ret"].copy_(ret)                               # (the GAE op returns fresh tensors every rollout)
+        if g["graph"] is None and g["warm"] < 3:
+            # eager passes first: lazy initialisations (Adam state, MIOpen solver choice, workspaces) must not be captured
+            g["warm"] += 1
+            gn = self._update_from(g["idx"], obs, masks, actions, g["old_logp"], g["adv"], g["ret"], old_values, dense, acc)
+            return gn
+        if g["graph"] is None:
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    g["gnorm"] = self._update_from(g["idx"], obs, masks, actions, g["old_logp"], g["adv"], g["ret"], old_values,
+                                                   dense, g["acc"])
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            g["graph"] = graph
+        g["acc"].zero_()
+        g["graph"].replay()
+        acc += g["acc"]
+        return g["gnorm"]
 
     # ------------------------------------------------------------------ checkpoints (ppo_agent.py:462-537 dict layout)
     def save_model(self, file_path, global_timestep=0, total_episodes_completed=0, stats_to_save=None):

@@ -435,3 +435,36 @@ def test_fused_policy_head_and_logits_path_learn_the_same_update():
         # Adam moves every weight by about lr per update whatever the gradient's size: compare at that scale
         assert float((a["params"] - b["params"]).abs().max()) < 4 * 3e-4 * 2
         assert float((a["params"] - b["params"]).abs().mean()) < 1e-5
+
+
+def test_graph_captured_minibatch_update_equals_the_eager_loop():
+    """PPOConfig.graph_minibatch_step: the per-minibatch optimizer update replayed from a hipGraph (three eager updates,
+    one capture, replays from then on, across two learn() calls with fresh advantages) against the eager loop."""
+    from shogidrl_amd.agent import PPOConfig, VecPPOAgent
+    from shogidrl_amd.buffer import VecExperienceBuffer
+    from shogidrl_amd.env import VecShogiEnv
+    from shogidrl_amd.models import ResTowerActorCritic
+    from shogidrl_amd.rollout import SelfPlayRunner
+    N, T = 64, 4
+    torch.backends.cudnn.deterministic = True
+    try:
+        res = []
+        for graphed in (False, True):
+            torch.manual_seed(0)
+            cfg = PPOConfig(ppo_epochs=2, minibatch_size=32, seed=4, graph_minibatch_step=graphed)
+            agent = VecPPOAgent(ResTowerActorCritic(46, A, 2, 32, 0.25), cfg, DEV)
+            run = SelfPlayRunner(VecShogiEnv(N, 40, device=DEV), agent, VecExperienceBuffer(T, N, cfg.gamma, cfg.lambda_gae, DEV))
+            ms = []
+            for _ in range(2):
+                run.collect()
+                ms.append(run.update())
+            res.append((ms, torch.cat([p.detach().reshape(-1) for p in agent.model.parameters()]).clone(),
+                        torch.cat([b.detach().reshape(-1).float() for b in agent.model.buffers()]).clone(), agent))
+    finally:
+        torch.backends.cudnn.deterministic = False
+    (m0, p0, b0, _), (m1, p1, b1, ag) = res
+    assert len(ag._step_graphs) == 1 and next(iter(ag._step_graphs.values()))["graph"] is not None
+    assert float((p0 - p1).abs().max()) < 2e-5 and float((b0 - b1).abs().max()) < 1e-4
+    for x, y in zip(m0, m1):
+        for k in ("ppo/policy_loss", "ppo/value_loss", "ppo/entropy", "ppo/kl_divergence_approx", "ppo/clip_fraction"):
+            assert abs(x[k] - y[k]) < 1e-4, k
