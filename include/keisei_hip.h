@@ -78,6 +78,19 @@ int ksh_env_max_moves(void *handle);
 int ksh_env_set_obs_format(void *handle, int obs_format);
 int ksh_env_obs_format(void *handle);
 
+/* Where the env kernel reads its 24.9 KB of attack tables from (a tuning switch, results are identical):
+ *   KSH_TABLES_LDS     every block stages a copy into LDS (33.6 KB of LDS per block, 4 waves per SIMD) -- faster up to
+ *                      ~32 768 games per GPU (4096 games: 24.6 vs 26.6 us per step)
+ *   KSH_TABLES_GLOBAL  lookups go to global memory (L1 / L2 resident; 9.4 KB of LDS, 7 waves per SIMD) -- faster at
+ *                      65 536 games (369 vs 387 us); float32 observation format only
+ *   KSH_TABLES_AUTO    the library's choice by n_games (the default at ksh_env_create; the environment variable
+ *                      KSH_ENV_TABLES=lds|global overrides it for A-B runs) */
+#define KSH_TABLES_AUTO 0
+#define KSH_TABLES_LDS 1
+#define KSH_TABLES_GLOBAL 2
+int ksh_env_set_table_mode(void *handle, int table_mode);
+int ksh_env_table_mode(void *handle);
+
 /* Reset the games whose reset_mask[g] != 0 (all games when reset_mask == NULL) to the initial position
  * and write obs / legal mask / legal-move count of EVERY game (non-reset games are re-observed). */
 int ksh_env_reset(void *handle, const uint8_t *reset_mask /*dev [N] or NULL*/, float *obs /*dev*/,

@@ -16,7 +16,7 @@ _lib = None
 # every symbol include/keisei_hip.h declares (tests check the .so exports each of them)
 SYMBOLS = [
     "ksh_last_error", "ksh_version", "ksh_env_create", "ksh_env_destroy", "ksh_env_num_games", "ksh_env_max_moves",
-    "ksh_env_set_obs_format", "ksh_env_obs_format",
+    "ksh_env_set_obs_format", "ksh_env_obs_format", "ksh_env_set_table_mode", "ksh_env_table_mode",
     "ksh_env_reset", "ksh_env_observe", "ksh_env_evaluate_termination", "ksh_env_step", "ksh_env_reset_packed", "ksh_env_step_packed", "ksh_env_set_state", "ksh_env_get_state", "ksh_masked_sample", "ksh_masked_sample_packed", "ksh_masked_sample_graph", "ksh_ppo_loss_fwd_bwd_packed",
     "ksh_evaluate_actions", "ksh_evaluate_actions_workspace_bytes",
     "ksh_pack_mask", "ksh_policy_head_sample", "ksh_policy_head_evaluate", "ksh_policy_head_evaluate_workspace_bytes",
@@ -57,6 +57,8 @@ def lib():
     L.ksh_env_max_moves.argtypes = [vp]
     L.ksh_env_set_obs_format.argtypes = [vp, C.c_int]
     L.ksh_env_obs_format.argtypes = [vp]
+    L.ksh_env_set_table_mode.argtypes = [vp, C.c_int]
+    L.ksh_env_table_mode.argtypes = [vp]
     L.ksh_env_reset.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ksh_env_observe.argtypes = [vp, vp, vp, vp, vp]
     L.ksh_env_evaluate_termination.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]

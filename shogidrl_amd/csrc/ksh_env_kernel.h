@@ -984,5 +984,5 @@ __device__ __forceinline__ void ksh_env_step_body(const KshStepArgs &a) {
 // Two entry points over one body: the reference contract (float32 planes, NCHW) and the compact observation format.
 extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_kernel(KshStepArgs a) { ksh_env_step_body<0, 0>(a); }
 extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_c16_kernel(KshStepArgs a) { ksh_env_step_body<1, 0>(a); }
-// same step, attack tables read from global memory instead of an LDS copy (ksh_env_set_table_mode)
+// same step, attack tables read from global memory instead of an LDS copy (ksh_env_set_table_mode, include/keisei_hip.h)
 extern "C" __global__ void __launch_bounds__(64 * KSH_WPB) ksh_env_step_gt_kernel(KshStepArgs a) { ksh_env_step_body<0, 1>(a); }

@@ -114,6 +114,18 @@ int ksh_env_set_obs_format(void *handle, int obs_format) {
 }
 int ksh_env_obs_format(void *handle) { return handle ? ((KshEnv *)handle)->obs_format : KSH_E_ARG; }
 
+int ksh_env_set_table_mode(void *handle, int table_mode) {
+    if (!handle) return fail_arg("ksh_env_set_table_mode: null handle");
+    KshEnv *e = (KshEnv *)handle;
+    if (table_mode == KSH_TABLES_AUTO) e->table_mode = e->n >= 65536 ? 1 : 0;
+    else if (table_mode == KSH_TABLES_LDS || table_mode == KSH_TABLES_GLOBAL) e->table_mode = table_mode == KSH_TABLES_GLOBAL ? 1 : 0;
+    else return fail_arg("ksh_env_set_table_mode: unknown mode");
+    return KSH_OK;
+}
+int ksh_env_table_mode(void *handle) {
+    return handle ? (((KshEnv *)handle)->table_mode ? KSH_TABLES_GLOBAL : KSH_TABLES_LDS) : KSH_E_ARG;
+}
+
 static unsigned long long *g_stamps = nullptr;  // diagnostic builds only (ksh_debug_set_stamps)
 
 static int launch_env(KshEnv *e, int mode, const int64_t *actions, const uint8_t *prev_mask, const uint8_t *reset_mask,

@@ -44,7 +44,7 @@ def _obs_dense(obs, obs_format):
 
 class VecShogiEnv:
     def __init__(self, num_games, max_moves_per_game=500, device="cuda:0", auto_reset=True, packed_masks=False,
-                 obs_format="f32", emit_bits=True):
+                 obs_format="f32", emit_bits=True, table_mode="auto"):
         """obs_format="bf16_nhwc": observations are written as bfloat16 in channels_last memory format (7 452 B per
         game instead of 14 904) -- tensors still have shape [N,46,9,9] and equal
         `obs_f32.to(torch.bfloat16)` bit for bit; see `empty_obs`.
@@ -52,7 +52,9 @@ class VecShogiEnv:
         contract, utils/utils.py:310-336) and the same set as `legal_bits` (int32 [N,424], 1 696 B per game, +6 % bytes):
         the sampler / loss kernels read the bit-set instead of re-reading the 13.5 KB byte row it was expanded from.
         emit_bits=False: byte mask only (the round-1 contract path, kept for A/B measurements).
-        packed_masks=True: ONLY the bit-packed form; `legal_mask` is then unavailable."""
+        packed_masks=True: ONLY the bit-packed form; `legal_mask` is then unavailable.
+        table_mode: "auto" | "lds" | "global" -- where the kernel reads its attack tables from (ksh_env_set_table_mode;
+        a tuning switch, identical results)."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.KeiseiHipError("VecShogiEnv runs on an MI355X only (device=%r); there is no CPU path" % (device,))
@@ -71,6 +73,8 @@ class VecShogiEnv:
             raise ValueError("obs_format must be one of %r" % (tuple(OBS_FORMATS),))
         self.obs_format = obs_format
         check(self._L.ksh_env_set_obs_format(self._h, OBS_FORMATS[obs_format]), "ksh_env_set_obs_format")
+        if table_mode != "auto":
+            check(self._L.ksh_env_set_table_mode(self._h, {"lds": 1, "global": 2}[table_mode]), "ksh_env_set_table_mode")
         self.obs = empty_obs((n,), obs_format, dev)
         self.packed_masks = bool(packed_masks)
         self.emit_bits = bool(emit_bits) or self.packed_masks

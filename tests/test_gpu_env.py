@@ -177,3 +177,24 @@ def test_gpu_compact_bf16_channels_last_obs():
         m32, m16 = e32.legal_mask, e16.legal_mask
     with pytest.raises(ValueError):
         e16.step(a, out_obs=torch.empty((n, 46, 9, 9), dtype=torch.bfloat16, device="cuda"))   # NCHW block: wrong layout
+
+
+def test_gpu_table_modes_give_identical_results():
+    """ksh_env_set_table_mode: attack tables from the LDS copy or from global memory -- a tuning switch, bit-identical outputs"""
+    import torch
+    from shogidrl_amd import ops
+    from shogidrl_amd.env import VecShogiEnv
+    N = 512
+    envs = [VecShogiEnv(N, 120, table_mode=m) for m in ("lds", "global")]
+    assert envs[0]._L.ksh_env_table_mode(envs[0]._h) == 1 and envs[1]._L.ksh_env_table_mode(envs[1]._h) == 2
+    for e in envs:
+        e.reset()
+    zeros = torch.zeros(N, 13527, device="cuda:0")
+    for t in range(150):
+        a, _ = ops.masked_sample(zeros, envs[0].legal_bits, 9, t)
+        for e in envs:
+            e.step(a)
+        assert torch.equal(envs[0].obs, envs[1].obs) and torch.equal(envs[0].legal_mask, envs[1].legal_mask), t
+        assert torch.equal(envs[0].legal_bits, envs[1].legal_bits) and torch.equal(envs[0].done, envs[1].done)
+        assert torch.equal(envs[0].reason, envs[1].reason) and torch.equal(envs[0].reward, envs[1].reward)
+    assert int(envs[0].done.sum()) >= 0
