@@ -203,3 +203,52 @@ def test_fused_head_rejects_unsupported_shapes():
         O.policy_head_sample(torch.zeros(2, 162, device=dev).half(), torch.zeros(A, 162, device=dev), None, mask, 1, 0)
     with pytest.raises(KeiseiHipError):
         O.policy_head_sample(torch.zeros(2, 162), torch.zeros(A, 162), None, mask.cpu(), 1, 0)                         # CPU tensors: no CPU path
+
+
+def test_gpu_fused_head_at_production_size_against_plain_pytorch_autograd():
+    """4096 rows of self-play masks, K = 162: the fused op against the REFERENCE'S OWN arithmetic written in plain PyTorch
+    float32 on the GPU (evaluate_actions: where(mask, logits, -inf) -> softmax -> Categorical(probs) log_prob / entropy,
+    base_actor_critic.py:139-184; PPOAgent.learn's loss lines, ppo_agent.py:340-383) and torch.autograd's gradients."""
+    from shogidrl_amd import ops as O
+    from shogidrl_amd.env import VecShogiEnv
+    torch.manual_seed(2)
+    N, K, dev = 4096, 162, "cuda:0"
+    env = VecShogiEnv(N, 500, device=dev)
+    env.reset()
+    zeros = torch.zeros(N, A, device=dev)
+    for t in range(40):
+        a, _ = O.masked_sample(zeros, env.legal_bits, 11, t)
+        env.step(a)
+    del zeros
+    bits, mask = env.legal_bits, env.legal_mask
+    feat = torch.randn(N, K, device=dev)
+    W = torch.randn(A, K, device=dev) * 0.12
+    b = torch.randn(A, device=dev) * 0.2
+    values, adv, ret = torch.randn(N, device=dev), torch.randn(N, device=dev), torch.randn(N, device=dev)
+    old_values = values + 0.3 * torch.randn(N, device=dev)
+    actions, lp = O.policy_head_sample(feat, W, b, bits, 3, 1)
+    old_lp = lp + 0.15 * torch.randn(N, device=dev)
+    for value_clip in (False, True):
+        stats, dfeat, dW, dbias, dval = O.policy_head_loss_grads(feat, W, b, values, bits, actions, old_lp, adv, ret, old_values,
+                                                                 0.2, 0.5, 0.01, value_clip, dense_rows_possible=False)
+        f, w, bb, v = (t.clone().requires_grad_(True) for t in (feat, W, b, values))
+        logits = f @ w.t() + bb
+        probs = torch.softmax(torch.where(mask, logits, torch.full_like(logits, float("-inf"))), dim=-1)
+        dist = torch.distributions.Categorical(probs=probs)
+        new_lp, ent = dist.log_prob(actions), dist.entropy()
+        ratio = torch.exp(new_lp - old_lp)
+        policy_loss = -torch.min(ratio * adv, torch.clamp(ratio, 0.8, 1.2) * adv).mean()
+        if value_clip:
+            vc = old_values + torch.clamp(v - old_values, -0.2, 0.2)
+            value_loss = torch.max(torch.nn.functional.mse_loss(v, ret), torch.nn.functional.mse_loss(vc, ret))
+        else:
+            value_loss = torch.nn.functional.mse_loss(v, ret)
+        entropy_loss = -ent.mean()
+        loss = policy_loss + 0.5 * value_loss + 0.01 * entropy_loss
+        loss.backward()
+        want = [float(x.detach()) for x in (loss, policy_loss, value_loss, entropy_loss, (old_lp - new_lp).mean(),
+                                   ((ratio - 1.0).abs() > 0.2).float().mean())]
+        np.testing.assert_allclose(stats[:6].cpu().numpy(), want, rtol=1e-4, atol=2e-6)
+        for got, ref, name in ((dfeat, f.grad, "dfeat"), (dW, w.grad, "dW"), (dbias, bb.grad, "dbias"), (dval, v.grad, "dvalues")):
+            err = float((got - ref).abs().max())
+            assert err <= 3e-4 * float(ref.abs().max()) + 1e-8, (name, value_clip, err, float(ref.abs().max()))
