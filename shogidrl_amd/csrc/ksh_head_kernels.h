@@ -28,7 +28,9 @@
 
 #include "ksh_ppo_kernels.h"
 
+#ifndef KSH_HEAD_WPB
 #define KSH_HEAD_WPB 4      // waves (= rows) per block of the row kernels
+#endif
 #define KSH_HEAD_CAP 1024   // legal ids per row the sparse path holds (Shogi's maximum is 593)
 
 struct KshHeadArgs {
@@ -426,8 +428,9 @@ __global__ void __launch_bounds__(64 * KSH_HEAD_WPB) ksh_head_loss_kernel(KshHea
 //            table[a] remembers where a heavy action's items start.
 //   work     a fixed-size grid of waves walks the list; an item's samples are visited in ascending order, T feature
 //            rows in flight.  A light item writes dW[a] / dbias[a] directly, a segment its partial row to scratch.
-//   combine  one wave per action: heavy actions add their partial rows in segment order; actions that were legal
-//            nowhere get their zero row here -- which IS the zero-fill of the gradient; light ones are already done.
+//   combine  one wave per action: heavy actions add their partial rows in segment order (everything else returns at once:
+//            light rows were written by the work kernel, the zero rows of never-legal actions -- the zero-fill of the
+//            gradient -- by the scan kernel).
 // Every sum has a fixed order, so the result is bit-reproducible and independent of scheduling.
 struct KshHeadDwArgs {
     const float *feat;       // [B][K]
@@ -449,45 +452,70 @@ struct KshHeadDwArgs {
 #define KSH_DW_SCAN_WPB 16
 #define KSH_DW_ALL 31u
 
+#define KSH_DW_SCAN_APW 4      // actions per wave of the scan kernel (their bit-row loads are issued together)
+
 extern "C" __global__ void __launch_bounds__(64 * KSH_DW_SCAN_WPB) ksh_head_dw_scan_kernel(KshHeadDwArgs a) {
-    __shared__ int s_cnt[KSH_DW_SCAN_WPB];
+    __shared__ int s_cnt[KSH_DW_SCAN_WPB][KSH_DW_SCAN_APW];
     __shared__ int s_base;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int j = blockIdx.x * KSH_DW_SCAN_WPB + wv;
-    uint32_t m = 0;
-    int total = 0;
-    if (j < a.A) {   // wave-uniform
-        const uint32_t *brow = a.bitsT + (size_t)j * (size_t)a.BW;
-        for (int d = lane; d < a.BW; d += 64) {
-            const uint32_t w = brow[d];
-            if (w != 0u) { m |= 1u << (d / a.SEGW); total += __popc(w); }
-        }
+    const int j0 = (blockIdx.x * KSH_DW_SCAN_WPB + wv) * KSH_DW_SCAN_APW;
+    uint32_t m[KSH_DW_SCAN_APW];
+    int total[KSH_DW_SCAN_APW];
+#pragma unroll
+    for (int q = 0; q < KSH_DW_SCAN_APW; q++) { m[q] = 0u; total[q] = 0; }
+    for (int d = lane; d < a.BW; d += 64) {              // wave-uniform trip count; 4 independent loads per round
+        uint32_t w[KSH_DW_SCAN_APW];
+#pragma unroll
+        for (int q = 0; q < KSH_DW_SCAN_APW; q++) w[q] = j0 + q < a.A ? a.bitsT[(size_t)(j0 + q) * (size_t)a.BW + (size_t)d] : 0u;
+#pragma unroll
+        for (int q = 0; q < KSH_DW_SCAN_APW; q++)
+            if (w[q] != 0u) { m[q] |= 1u << (d / a.SEGW); total[q] += __popc(w[q]); }
+    }
+#pragma unroll
+    for (int q = 0; q < KSH_DW_SCAN_APW; q++) {
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
-            m |= (uint32_t)__shfl_xor((int)m, o);
-            total += __shfl_xor(total, o);
+            m[q] |= (uint32_t)__shfl_xor((int)m[q], o);
+            total[q] += __shfl_xor(total[q], o);
         }
     }
-    const bool light = total > 0 && total <= a.light_max;
-    const int mine = total == 0 ? 0 : (light ? 1 : __popc(m));
-    if (lane == 0) s_cnt[wv] = mine;
+    bool light[KSH_DW_SCAN_APW];
+#pragma unroll
+    for (int q = 0; q < KSH_DW_SCAN_APW; q++) {
+        light[q] = total[q] > 0 && total[q] <= a.light_max;
+        if (lane == 0) s_cnt[wv][q] = total[q] == 0 ? 0 : (light[q] ? 1 : __popc(m[q]));
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         int sum = 0;
-        for (int w = 0; w < KSH_DW_SCAN_WPB; w++) sum += s_cnt[w];
-        s_base = sum ? (int)atomicAdd(a.n_items, (unsigned)sum) : 0;
+        for (int w = 0; w < KSH_DW_SCAN_WPB; w++)
+            for (int q = 0; q < KSH_DW_SCAN_APW; q++) sum += s_cnt[w][q];
+        s_base = sum ? (int)atomicAdd(a.n_items, (unsigned)sum) : 0;      // ONE atomic per 64 actions
     }
     __syncthreads();
-    if (j >= a.A) return;
     int base = s_base;
-    for (int w = 0; w < wv; w++) base += s_cnt[w];
-    if (light) {
-        if (lane == 0) a.items[base] = (uint32_t)j * 32u + KSH_DW_ALL;
-    } else if (lane < 16 && ((m >> lane) & 1u)) {
-        a.items[base + __popc(m & ((1u << lane) - 1u))] = (uint32_t)j * 32u + (uint32_t)lane;
+    for (int w = 0; w < wv; w++)
+        for (int q = 0; q < KSH_DW_SCAN_APW; q++) base += s_cnt[w][q];
+    const int nq = a.K >> 2;
+    const bool tail = (a.K & 2) != 0;
+#pragma unroll
+    for (int q = 0; q < KSH_DW_SCAN_APW; q++) {
+        const int j = j0 + q;
+        if (j >= a.A) break;                              // wave-uniform
+        if (total[q] == 0) {
+            // legal nowhere in this minibatch: its zero row -- the zero-fill of the gradient -- is written here
+            float2 *drow = reinterpret_cast<float2 *>(a.dW + (size_t)j * (size_t)a.K);
+            for (int p = lane; p < 2 * nq + (tail ? 1 : 0); p += 64) drow[p] = make_float2(0.0f, 0.0f);
+            if (lane == 0 && a.dbias != nullptr) a.dbias[j] = 0.0f;
+        } else if (light[q]) {
+            if (lane == 0) a.items[base] = (uint32_t)j * 32u + KSH_DW_ALL;
+        } else if (lane < 16 && ((m[q] >> lane) & 1u)) {
+            a.items[base + __popc(m[q] & ((1u << lane) - 1u))] = (uint32_t)j * 32u + (uint32_t)lane;
+        }
+        if (lane == 0) { a.table[2 * j] = base; a.table[2 * j + 1] = total[q] == 0 ? 0 : (light[q] ? (int)0x80000000u : (int)m[q]); }
+        base += total[q] == 0 ? 0 : (light[q] ? 1 : __popc(m[q]));
     }
-    if (lane == 0) { a.table[2 * j] = base; a.table[2 * j + 1] = light ? (int)0x80000000u : (int)m; }
 }
 
 #define KSH_DW_WIN 256   // samples per LDS window of the work kernel
@@ -597,7 +625,8 @@ __global__ void __launch_bounds__(64 * KSH_DW_WPB) ksh_head_dw_combine_kernel(Ks
     const bool tail = (a.K & 2) != 0;
     const int base = a.table[2 * j];
     const unsigned tm = (unsigned)a.table[2 * j + 1];
-    if (tm & 0x80000000u) return;                           // light action: the work kernel wrote its row (wave-uniform)
+    if (tm == 0u || (tm & 0x80000000u)) return;             // legal nowhere: the scan kernel wrote its zero row; light: the
+                                                            // work kernel wrote its row (wave-uniform)
     const int cnt = __popc(tm);
     float4 acc[QQ];
 #pragma unroll

@@ -544,7 +544,8 @@ static int head_loss_impl(const float *feat, const float *W, const float *bias, 
         d.light_max = 64;
         if (const char *lm = getenv("KSH_HEAD_LIGHT_MAX")) d.light_max = atoi(lm);     // tuning switch (tools/headdiag.py)
         const dim3 ag((KSH_PA + KSH_DW_WPB - 1) / KSH_DW_WPB), ab(64 * KSH_DW_WPB);
-        hipLaunchKernelGGL(ksh_head_dw_scan_kernel, dim3((KSH_PA + KSH_DW_SCAN_WPB - 1) / KSH_DW_SCAN_WPB),
+        hipLaunchKernelGGL(ksh_head_dw_scan_kernel,
+                           dim3((KSH_PA + KSH_DW_SCAN_WPB * KSH_DW_SCAN_APW - 1) / (KSH_DW_SCAN_WPB * KSH_DW_SCAN_APW)),
                            dim3(64 * KSH_DW_SCAN_WPB), 0, st, d);
         // a fixed grid walks the work list (its length is only known on the device): 2048 blocks = 8192 waves
         if (K <= 192) {
