@@ -212,7 +212,7 @@ int ksh_evaluate_actions(const void *logits /*dev [B,A]*/, int logits_dtype, con
  *   + get_action_and_value's tail                         core/base_actor_critic.py:64-116   -> ksh_policy_head_sample
  *   + evaluate_actions' tail                              core/base_actor_critic.py:139-184  -> ksh_policy_head_evaluate
  *   + PPOAgent.learn's loss lines and their autograd      core/ppo_agent.py:340-383          -> ksh_policy_head_loss_fwd_bwd
- * feat  float32 [B,K]  the Linear layer's input (K even, <= 1312; 162 for the ResNet tower), 8-byte aligned
+ * feat  float32 [B,K]  the Linear layer's input (K even, 4 <= K <= 1312; 162 for the ResNet tower), 8-byte aligned
  * W     float32 [13527,K] = nn.Linear.weight,  bias float32 [13527] (or NULL) = nn.Linear.bias
  * mask_bits uint32 [B,424]  packed legal masks (KSH_MASK_WORDS; ksh_pack_mask converts bool[13527] rows)
  * Sparse rows (<= 1024 legal actions; a Shogi position has at most 593) gather only the legal rows of W; rows with

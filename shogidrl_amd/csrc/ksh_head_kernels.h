@@ -70,9 +70,8 @@ __device__ __forceinline__ int ksh_head_collect(const uint32_t *__restrict__ bro
 #pragma unroll
     for (int it = 0; it < 7; it++) {
         const int i = 7 * lane + it;
-        uint32_t v = i < KSH_PBITROW ? brow[i] : 0u;
-        if (i == 422) v &= 0x007FFFFFu;   // bits >= 13527 never count
-        if (i >= 423) v = 0u;
+        uint32_t v = brow[i < KSH_PBITROW ? i : KSH_PBITROW - 1];     // unconditional load (clamped), masked below
+        v = i < 422 ? v : (i == 422 ? (v & 0x007FFFFFu) : 0u);        // bits >= 13527 never count
         wd[it] = v;
         c += __popc(v);
     }
@@ -104,60 +103,77 @@ __device__ __forceinline__ int ksh_head_collect(const uint32_t *__restrict__ bro
 struct __attribute__((packed, aligned(8))) ksh_f4a8 {
     float x, y, z, w;
 };
+// BRANCH-FREE on purpose: one unconditional 16-byte load per call and selects afterwards.  (A version with an `if` per
+// case compiled into exec-mask branches with an s_waitcnt vmcnt(0) behind EVERY load -- the gathers of a wave then ran
+// one after the other, which is what the first ISA dump of the row kernel showed.)  The trailing pair is fetched as
+// the upper half of the quad that ENDS at the row's end (elements K-4 .. K-1), so no load ever leaves the row; lanes
+// beyond the row read its first quad and discard it.  Needs K >= 4.
 __device__ __forceinline__ float4 ksh_ld_quad(const float *row, int q, int nq, bool tail) {
-    if (q < nq) {
-        const ksh_f4a8 v = reinterpret_cast<const ksh_f4a8 *>(row)[q];
-        return make_float4(v.x, v.y, v.z, v.w);
-    }
-    if (q == nq && tail) {
-        const float2 v = reinterpret_cast<const float2 *>(row)[2 * q];
-        return make_float4(v.x, v.y, 0.0f, 0.0f);
-    }
-    return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const bool full = q < nq;
+    const bool last = q == nq && tail;
+    const int off = full ? 4 * q : (last ? 4 * nq - 2 : 0);
+    const ksh_f4a8 v = *reinterpret_cast<const ksh_f4a8 *>(row + off);
+    // bit masks, not selects: every component of the load is consumed unconditionally, so the compiler cannot split the
+    // load and sink parts of it into branches again
+    const uint32_t mf = full ? 0xFFFFFFFFu : 0u, ml = last ? 0xFFFFFFFFu : 0u;
+    const uint32_t x = __float_as_uint(v.x), y = __float_as_uint(v.y), z = __float_as_uint(v.z), w = __float_as_uint(v.w);
+    return make_float4(ksh_u2f((x & mf) | (z & ml)), ksh_u2f((y & mf) | (w & ml)), ksh_u2f(z & mf), ksh_u2f(w & mf));
 }
 
 // z_e = <feat, W[list[e]]> + bias for the first n list entries.  8 lanes per action: lane s of a sub-group owns the
 // quads q = s, s+8, ... of a row (8 lanes x 16 B = one 128-byte line per load instruction and sub-group); every
 // sub-group works on TWO actions at once (e and e+8), CH quads each, so 2*CH independent 16-byte loads are in flight
 // per lane before the first multiply.  feat: this wave's feature row in LDS (16-byte aligned, zero-padded to KMAX).
+#ifndef KSH_HEAD_NA
+#define KSH_HEAD_NA 2      // actions per sub-group and round of ksh_head_logits (1 and 3 measured: profiles/r02_head_kernels_pmc.txt)
+#endif
 template <int KMAX>
 __device__ __forceinline__ void ksh_head_logits(const KshHeadArgs &a, const float *feat, const unsigned short *list, int n,
                                                 int lane, float *z) {
     constexpr int CH = (KMAX / 4 + 7) / 8 < 6 ? (KMAX / 4 + 7) / 8 : 6;   // quads per lane and chunk
+    constexpr int NA = KSH_HEAD_NA;
     const int s = lane & 7, g = lane >> 3;
     const int nq = a.K >> 2;
     const bool tail = (a.K & 2) != 0;
     const int nqt = nq + (tail ? 1 : 0);
     const float4 *f4 = reinterpret_cast<const float4 *>(feat);
-    for (int e0 = 0; e0 < n; e0 += 16) {           // wave-uniform trip count
-        const int eA = e0 + g, eB = e0 + 8 + g;
-        const int jA = (int)list[eA < n ? eA : 0], jB = (int)list[eB < n ? eB : 0];
-        const float *rA = a.W + (size_t)jA * (size_t)a.K, *rB = a.W + (size_t)jB * (size_t)a.K;
-        float accA = 0.0f, accB = 0.0f;
+    for (int e0 = 0; e0 < n; e0 += 8 * NA) {       // wave-uniform trip count
+        int e[NA], j[NA];
+        const float *r[NA];
+        float acc[NA];
+#pragma unroll
+        for (int u = 0; u < NA; u++) {
+            e[u] = e0 + 8 * u + g;
+            j[u] = (int)list[e[u] < n ? e[u] : 0];
+            r[u] = a.W + (size_t)j[u] * (size_t)a.K;
+            acc[u] = 0.0f;
+        }
         for (int c0 = 0; c0 < nqt; c0 += 8 * CH) {  // one round for K = 162
-            float4 wA[CH], wB[CH];
+            float4 w[NA][CH];
 #pragma unroll
             for (int c = 0; c < CH; c++) {
-                wA[c] = ksh_ld_quad(rA, c0 + s + 8 * c, nq, tail);
-                wB[c] = ksh_ld_quad(rB, c0 + s + 8 * c, nq, tail);
+#pragma unroll
+                for (int u = 0; u < NA; u++) w[u][c] = ksh_ld_quad(r[u], c0 + s + 8 * c, nq, tail);
             }
 #pragma unroll
             for (int c = 0; c < CH; c++) {
                 const int q = c0 + s + 8 * c;
                 const float4 f = q < nqt ? f4[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                accA = fmaf(wA[c].x, f.x, accA); accA = fmaf(wA[c].y, f.y, accA);
-                accA = fmaf(wA[c].z, f.z, accA); accA = fmaf(wA[c].w, f.w, accA);
-                accB = fmaf(wB[c].x, f.x, accB); accB = fmaf(wB[c].y, f.y, accB);
-                accB = fmaf(wB[c].z, f.z, accB); accB = fmaf(wB[c].w, f.w, accB);
+#pragma unroll
+                for (int u = 0; u < NA; u++) {
+                    acc[u] = fmaf(w[u][c].x, f.x, acc[u]); acc[u] = fmaf(w[u][c].y, f.y, acc[u]);
+                    acc[u] = fmaf(w[u][c].z, f.z, acc[u]); acc[u] = fmaf(w[u][c].w, f.w, acc[u]);
+                }
             }
         }
 #pragma unroll
         for (int o = 1; o <= 4; o <<= 1) {
-            accA += __shfl_xor(accA, o);
-            accB += __shfl_xor(accB, o);
+#pragma unroll
+            for (int u = 0; u < NA; u++) acc[u] += __shfl_xor(acc[u], o);
         }
-        if (s == 0 && eA < n) z[eA] = accA + (a.bias != nullptr ? a.bias[jA] : 0.0f);
-        if (s == 0 && eB < n) z[eB] = accB + (a.bias != nullptr ? a.bias[jB] : 0.0f);
+#pragma unroll
+        for (int u = 0; u < NA; u++)
+            if (s == 0 && e[u] < n) z[e[u]] = acc[u] + (a.bias != nullptr ? a.bias[j[u]] : 0.0f);
     }
     ksh_head_wave_sync();
 }
@@ -375,7 +391,7 @@ __global__ void __launch_bounds__(64 * KSH_HEAD_WPB) ksh_head_loss_kernel(KshHea
     // lane for K = 162), U entries' loads in flight at once
     {
         constexpr int QQ = (KMAX / 4 + 63) / 64;
-        constexpr int U = QQ == 1 ? 8 : 2;      // (16 in flight measured no faster: profiles/r02_head_kernels_pmc.txt)
+        constexpr int U = QQ == 1 ? 4 : 2;      // (8 / 12 / 16 in flight measured no faster: profiles/r02_head_kernels_pmc.txt)
         const int nq = a.K >> 2;
         const bool tail = (a.K & 2) != 0;
         float4 acc[QQ];
@@ -523,7 +539,7 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_DW_SCAN_WPB) ksh_head_dw_s
 template <int KMAX>
 __global__ void __launch_bounds__(64 * KSH_DW_WPB) ksh_head_dw_work_kernel(KshHeadDwArgs a) {
     constexpr int QQ = (KMAX / 4 + 63) / 64;
-    constexpr int T = QQ == 1 ? 8 : 2;      // (4 / 16 in flight measure the same, 32 slower: profiles/r02_head_kernels_pmc.txt)
+    constexpr int T = QQ == 1 ? 4 : 2;      // (2 / 8 / 16 in flight measured slower: profiles/r02_head_kernels_pmc.txt)
     __shared__ int s_rows[KSH_DW_WPB][KSH_DW_WIN];
     __shared__ float s_dz[KSH_DW_WPB][KSH_DW_WIN];
     const int lane = threadIdx.x & 63;
@@ -580,14 +596,13 @@ __global__ void __launch_bounds__(64 * KSH_DW_WPB) ksh_head_dw_work_kernel(KshHe
                     for (int t = 0; t < T; t++) {
                         const bool on = e0 + t < cw;
                         dz[t] = on ? dzl[e0 + t] : 0.0f;
-                        const float *frow = a.feat + (size_t)(on ? rows[e0 + t] : 0) * (size_t)a.K;
+                        const float *frow = a.feat + (size_t)(on ? rows[e0 + t] : rows[e0]) * (size_t)a.K;
 #pragma unroll
-                        for (int i = 0; i < QQ; i++)
-                            f[t][i] = on ? ksh_ld_quad(frow, lane + 64 * i, nq, tail) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        for (int i = 0; i < QQ; i++) f[t][i] = ksh_ld_quad(frow, lane + 64 * i, nq, tail);   // (dz = 0 when off)
                     }
 #pragma unroll
                     for (int t = 0; t < T; t++) {
-                        if (e0 + t < cw) {
+                        if (e0 + t < cw) {                          // wave-uniform: keeps the sums free of "+ 0 * x" terms
                             dzsum += dz[t];
 #pragma unroll
                             for (int i = 0; i < QQ; i++) {

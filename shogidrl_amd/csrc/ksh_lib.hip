@@ -466,7 +466,7 @@ int ksh_pack_mask(const uint8_t *mask, int B, uint32_t *mask_bits, void *stream)
 
 static int head_common_ok(const char *who, const void *feat, const void *W, int K, const void *bits, int B) {
     if (!feat || !W || !bits || B <= 0) { g_err = std::string(who) + ": null pointer or B <= 0"; return 0; }
-    if (K <= 0 || (K & 1) != 0 || K > 1312) { g_err = std::string(who) + ": K must be even and <= 1312"; return 0; }
+    if (K < 4 || (K & 1) != 0 || K > 1312) { g_err = std::string(who) + ": K must be even, >= 4 and <= 1312"; return 0; }
     if ((reinterpret_cast<size_t>(feat) & 7) != 0 || (reinterpret_cast<size_t>(W) & 7) != 0) {
         g_err = std::string(who) + ": feat / W must be 8-byte aligned";
         return 0;

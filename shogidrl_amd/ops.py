@@ -199,8 +199,8 @@ def _head_args(feat, weight, bias, legal_mask):
     B, K = feat.shape
     if weight.shape != (NUM_ACTIONS, K) or (bias is not None and bias.shape != (NUM_ACTIONS,)):
         raise ValueError("weight must be [13527, K] and bias [13527] for features [B, K]")
-    if K % 2 or K > 1312:
-        raise ValueError("the fused policy head needs an even K <= 1312, got %d" % K)
+    if K % 2 or K < 4 or K > 1312:
+        raise ValueError("the fused policy head needs an even K with 4 <= K <= 1312, got %d" % K)
     bits = legal_mask.contiguous() if is_packed(legal_mask) else pack_mask_bits(legal_mask)
     if bits.shape != (B, MASK_WORDS):
         raise ValueError("legal mask must have one row per feature row")

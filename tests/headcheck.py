@@ -18,7 +18,7 @@ HEAD_LOGP_ATOL = 5e-6      # log-probs when the logits themselves are float32 do
 def onehot_head(logits):
     """(feat, W) with feat @ W.T == logits exactly"""
     B = logits.shape[0]
-    K = B + (B & 1)
+    K = max(4, B + (B & 1))
     feat = np.zeros((B, K), np.float32)
     feat[np.arange(B), np.arange(B)] = 1.0
     W = np.zeros((A, K), np.float32)
@@ -152,9 +152,9 @@ def check_head_sample_distribution(ops, n_draws=4000, seed=11):
     m[ids] = True
     p, _ = ppo_oracle.masked_probs(row[None], m[None])
     Bn = 200
-    feat = np.zeros((Bn, 2), np.float32)
+    feat = np.zeros((Bn, 4), np.float32)
     feat[:, 0] = 1.0
-    W = np.zeros((A, 2), np.float32)
+    W = np.zeros((A, 4), np.float32)
     W[:, 0] = row
     counts = np.zeros(A)
     for s in range(n_draws // Bn):
