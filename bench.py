@@ -28,6 +28,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+if "--graph" not in sys.argv and "--async-learner" not in sys.argv:
+    # The default run contains ONE hipGraph: the minibatch-64 side figure's captured PPO update, which needs the runtime's
+    # AQL-packet capture off (PPOConfig.graph_minibatch_step says why).  Nothing in the timed region uses a graph, so the
+    # headline number is not touched by this; runs that replay rollout graphs (--graph, --async-learner) keep the default.
+    os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -103,7 +108,7 @@ def cpu_baseline(seconds):
                           "sample": "%d env steps in %.1f s on %d threads" % (nk, dk, share)}}
 
 
-def minibatch64_rate(agent, buf, dev, updates=64):
+def minibatch64_rate(agent, buf, dev, updates=64, note=lambda msg: None):
     """PPO update rate at the REFERENCE's minibatch size (default_config.yaml:88 `minibatch_size: 64`), on a bounded
     sample: `updates` optimizer updates of 64 samples each drawn from the rollout buffer (one epoch over 64 x updates
     samples), timed with hipEvents after the headline measurement.  Reported next to the GPU-sized minibatch of the
@@ -129,6 +134,7 @@ def minibatch64_rate(agent, buf, dev, updates=64):
         agent.learn(small)
         tm.stop()
         ms = tm.elapsed_ms()
+        note("minibatch-64: %d eager updates in %.1f ms" % (updates, ms))
     finally:
         agent.config.minibatch_size, agent.config.ppo_epochs = saved
     out = {"value": n / (ms * 1e-3), "unit": "PPO samples/s", "minibatch_size": 64, "updates": updates,
@@ -140,11 +146,14 @@ def minibatch64_rate(agent, buf, dev, updates=64):
     try:
         import copy
         import dataclasses
-        from shogidrl_amd.agent import VecPPOAgent
+        from shogidrl_amd.agent import UPDATE_GRAPH_ENV, VecPPOAgent
+        if os.environ.get(UPDATE_GRAPH_ENV) != "0":
+            raise RuntimeError("not measured: %s=0 is not set in this run" % UPDATE_GRAPH_ENV)
         gcfg = dataclasses.replace(agent.config, minibatch_size=64, ppo_epochs=1, graph_minibatch_step=True)
         ga = VecPPOAgent(copy.deepcopy(agent.model), gcfg, dev)
         ga.learn(small)                          # eager warm-up updates + capture
         torch.cuda.synchronize()
+        note("minibatch-64: update graph captured")
         tm.start()
         ga.learn(small)
         tm.stop()
@@ -355,6 +364,8 @@ def main():
     out = None
     if rank == 0:
         roof = env_roofline(dev, args.games, args.replay, 42)
+        torch.cuda.synchronize()
+        note("env kernel replay done (%.2f us per launch)" % roof["avg_launch_us"])
         out = {
             "metric": "env-steps/sec self-play + PPO samples/sec, 4096 games, 1/2/4/8 MI355X",
             "value": transitions / elapsed,
@@ -388,8 +399,11 @@ def main():
             "episodes": runner.episode_stats(),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["ppo_reference_minibatch64"] = minibatch64_rate(agent, buf, dev)
+            out["ppo_reference_minibatch64"] = minibatch64_rate(agent, buf, dev, note=note)
+            torch.cuda.synchronize()
+            note("minibatch-64 sample done")
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            note("cpu baseline done")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

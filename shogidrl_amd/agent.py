@@ -11,6 +11,7 @@ The network forward/backward stays in PyTorch-ROCm; everything after the logits 
 log-prob, entropy, the PPO loss and its gradient) runs in the HIP kernels of shogidrl_amd.ops.  Unlike the
 reference there are no per-step `.item()` host syncs: metrics accumulate on the device and are read once
 per learn() call."""
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -20,6 +21,9 @@ import torch
 from . import ops
 from .mapper import PolicyOutputMapper
 from .parallel import FlatGradBucket, all_reduce_mean_, check_equal_batches, global_advantage_moments, sync_buffers
+
+
+UPDATE_GRAPH_ENV = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"     # see PPOConfig.graph_minibatch_step
 
 
 @dataclass
@@ -58,6 +62,12 @@ class PPOConfig:
     # where the loop is launch-bound -- the reference's default minibatch_size of 64 (default_config.yaml:88): some 600
     # launches of a few microseconds each per update -- and changes nothing at GPU-sized minibatches.  Single rank, fused
     # policy head and a minibatch that divides the batch only; anything else takes the eager loop.
+    # REQUIRES the process to run with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (set before the first HIP call): with the HIP
+    # runtime's default AQL-packet capture, replays of this graph came back corrupted (garbage gradients, once a memory
+    # fault) as soon as some ten thousand eager launches had gone through the same stream in between -- the re-computation
+    # of the old log-probs at the start of the next learn() is enough.  Measured in profiles/r02_update_graph_corruption.txt;
+    # the much smaller rollout graph (SelfPlayRunner.collect_graphed) is not affected.  VecPPOAgent refuses the option without
+    # that setting.
     graph_minibatch_step: bool = False
     mixed_precision: bool = False          # bf16 autocast of the tower (the reference uses fp16 + GradScaler)
     channels_last: bool = False
@@ -159,6 +169,12 @@ class ActingPolicy(_Acting):
 class VecPPOAgent(_Acting):
     def __init__(self, model, config=None, device="cuda:0", group=None, name="PPOAgent"):
         self.config = config or PPOConfig()
+        if self.config.graph_minibatch_step and os.environ.get(UPDATE_GRAPH_ENV) != "0" \
+                and os.environ.get("KSH_UNSAFE_UPDATE_GRAPH") != "1":
+            raise RuntimeError(
+                "PPOConfig.graph_minibatch_step needs %s=0 in the environment before the process makes its first HIP call: with "
+                "the runtime's default packet capture, replays of the captured update graph are corrupted once ~10^4 eager "
+                "launches have run on the same stream (profiles/r02_update_graph_corruption.txt)" % UPDATE_GRAPH_ENV)
         self.device = torch.device(device)
         self.name = name
         self.model = model.to(self.device)

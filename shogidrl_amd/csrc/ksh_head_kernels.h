@@ -457,7 +457,7 @@ struct KshHeadDwArgs {
     int B, BW, K, A;
     int SEGW, NSEG;          // dwords per segment, segments per bit row (<= 16)
     int light_max;           // actions with at most this many legal samples are one work item
-    unsigned *n_items;       // work-list length (zeroed by the caller)
+    unsigned *n_items;       // [0] work-list length, [1] "work list corrupt" flag (both zeroed by the caller)
     uint32_t *items;         // [A * NSEG]  action * 32 + segment (segment 31 = the whole row, result written directly)
     int *table;              // [A][2]  first item, segment mask (0 = legal nowhere, bit 31 = light: done by the work kernel)
     float *partial;          // [A * NSEG][K] partial rows
@@ -546,7 +546,14 @@ __global__ void __launch_bounds__(64 * KSH_DW_WPB) ksh_head_dw_work_kernel(KshHe
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wave = blockIdx.x * KSH_DW_WPB + wv;
     const int nwaves = (int)gridDim.x * KSH_DW_WPB;
-    const int n_items = (int)*a.n_items;
+    int n_items = (int)*a.n_items;
+    // A work list that cannot be right (counter beyond the list's capacity, action id beyond the table: only possible if
+    // the scratch was not cleared or was overwritten) must neither send this kernel outside its buffers nor pass silently:
+    // the list is cut / the item skipped and n_items[1] raised, which makes the combine kernel poison the gradient with NaN.
+    if (n_items < 0 || n_items > a.A * a.NSEG) {
+        if (threadIdx.x == 0) a.n_items[1] = 1u;
+        n_items = 0;
+    }
     const int nq = a.K >> 2;
     const bool tail = (a.K & 2) != 0;
     int *rows = s_rows[wv];
@@ -554,6 +561,10 @@ __global__ void __launch_bounds__(64 * KSH_DW_WPB) ksh_head_dw_work_kernel(KshHe
     for (int it = wave; it < n_items; it += nwaves) {     // wave-uniform
         const uint32_t item = a.items[it];
         const int j = (int)(item >> 5), sg = (int)(item & 31u);
+        if (j >= a.A || (sg != (int)KSH_DW_ALL && sg >= a.NSEG)) {
+            if (lane == 0) a.n_items[1] = 1u;
+            continue;
+        }
         const bool whole = sg == (int)KSH_DW_ALL;
         const int d0 = whole ? 0 : sg * a.SEGW, d1 = whole ? a.BW : ((d0 + a.SEGW < a.BW) ? d0 + a.SEGW : a.BW);
         const uint32_t *brow = a.bitsT + (size_t)j * (size_t)a.BW;
@@ -638,6 +649,14 @@ __global__ void __launch_bounds__(64 * KSH_DW_WPB) ksh_head_dw_combine_kernel(Ks
     if (j >= a.A) return;  // wave-uniform
     const int nq = a.K >> 2;
     const bool tail = (a.K & 2) != 0;
+    if (j == 0 && a.n_items[1] != 0u) {
+        // the work kernel met an impossible work list (see there): the whole gradient is unusable, say so with NaNs in the
+        // row this wave owns (every other writer of row 0 finished with the previous kernel)
+        float2 *drow = reinterpret_cast<float2 *>(a.dW);
+        for (int p = lane; p < 2 * nq + (tail ? 1 : 0); p += 64) drow[p] = make_float2(NAN, NAN);
+        if (lane == 0 && a.dbias != nullptr) a.dbias[0] = NAN;
+        return;
+    }
     const int base = a.table[2 * j];
     const unsigned tm = (unsigned)a.table[2 * j + 1];
     if (tm == 0u || (tm & 0x80000000u)) return;             // legal nowhere: the scan kernel wrote its zero row; light: the

@@ -10,8 +10,10 @@ A = 13527
 
 
 def _lib():
-    subprocess.check_call(["make", "-C", _DIR, "-s"])
-    L = C.CDLL(os.path.join(_DIR, "libksh_emu.so"))
+    # KSH_EMU_ASAN=1 (with libasan preloaded into python, see the Makefile): the AddressSanitizer build of the same sources
+    name = "libksh_emu_asan.so" if os.environ.get("KSH_EMU_ASAN") == "1" else "libksh_emu.so"
+    subprocess.check_call(["make", "-C", _DIR, "-s", name])
+    L = C.CDLL(os.path.join(_DIR, name))
     L.emu_env_launch.argtypes = [C.c_void_p] * 15 + [C.c_int] * 6
     L.emu_build_tables.argtypes = [C.c_void_p, C.c_int]
     L.emu_finish_record.argtypes = [C.c_void_p, C.c_int]

@@ -51,3 +51,16 @@ def test_agent_checkpoint_round_trip_and_reference_keys(tmp_path):
     for (k1, v1), (k2, v2) in zip(a.model.state_dict().items(), b.model.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
     assert b.load_model(str(tmp_path / "missing.pth"))["error"] == "File not found"
+
+
+def test_update_graph_option_is_refused_without_the_runtime_setting(monkeypatch):
+    """PPOConfig.graph_minibatch_step needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (profiles/r02_update_graph_corruption.txt): the
+    constructor says so before it touches the device"""
+    from shogidrl_amd.agent import PPOConfig, VecPPOAgent
+    monkeypatch.delenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", raising=False)
+    monkeypatch.delenv("KSH_UNSAFE_UPDATE_GRAPH", raising=False)
+    with pytest.raises(RuntimeError, match="DEBUG_CLR_GRAPH_PACKET_CAPTURE"):
+        VecPPOAgent(TinyActorCritic(), PPOConfig(graph_minibatch_step=True), device="cpu")
+    monkeypatch.setenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1")
+    with pytest.raises(RuntimeError, match="DEBUG_CLR_GRAPH_PACKET_CAPTURE"):
+        VecPPOAgent(TinyActorCritic(), PPOConfig(graph_minibatch_step=True), device="cpu")

@@ -1,5 +1,6 @@
 """Fused policy-head kernel sources (shogidrl_amd/csrc/ksh_head_kernels.h) executed on the HOST through the fiber
 emulator (MFMA included), checked against the reference's golden vectors and the float64 oracle."""
+import numpy as np
 import pytest
 
 from tests import headcheck
@@ -36,6 +37,31 @@ def test_emu_head_loss_heavy_actions_split_into_segments_and_no_bias():
     o = EmuOps()
     o.wpa, o.light_max = 3, 1          # actions legal in one sample are light (written directly), the others heavy
     headcheck.check_head_loss_vs_oracle(o, 70, 162, seed=5, dense=False, with_bias=False)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_emu_head_corrupt_work_list_is_contained_and_poisons_the_gradient(mode):
+    """an impossible work list (counter far beyond the list: what an un-cleared scratch looks like; an item naming an action
+    beyond the table) must not take the work kernel outside its buffers (run this file under the AddressSanitizer build to
+    see that) and must not pass silently: row 0 of the weight gradient and dbias[0] come back NaN"""
+    from tests.emu import emu
+    rng = np.random.default_rng(3)
+    B, K, A = 6, 162, 13527
+    feat = rng.standard_normal((B, K)).astype(np.float32)
+    W = (rng.standard_normal((A, K)) * 0.1).astype(np.float32)
+    bias = rng.standard_normal(A).astype(np.float32)
+    mask = np.zeros((B, A), np.uint8)
+    for b in range(B):
+        mask[b, rng.choice(A, 30, replace=False)] = 1
+    actions = np.array([np.flatnonzero(mask[b])[0] for b in range(B)], np.int64)
+    z = np.zeros(B, np.float32)
+    emu._plib().emu_head_corrupt_work_list(mode)
+    try:
+        dfeat, dW, dbias, dv, st = ops.head_loss(feat, W, bias, mask, actions, z - 1.0, z + 1.0, z, z, None, 0.2, 0.5, 0.01, False,
+                                                 dense=False)
+    finally:
+        emu._plib().emu_head_corrupt_work_list(0)
+    assert np.isnan(dW[0]).all() and np.isnan(dbias[0])
 
 
 def test_emu_head_evaluate():
