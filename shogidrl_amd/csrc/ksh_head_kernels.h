@@ -382,9 +382,8 @@ __global__ void __launch_bounds__(64 * KSH_HEAD_WPB) ksh_head_loss_kernel(KshHea
         const float y = expf(z[e] - m) * inv_s;
         const bool u = (y >= KSH_EPS) && (y <= 1.0f - KSH_EPS);
         const float l = logf(fminf(fmaxf(y, KSH_EPS), 1.0f - KSH_EPS));
-        float G = ce * (l + (u ? 1.0f : 0.0f));
-        if ((int)list[e] == act) G += pol / y;
-        z[e] = y * (G - c);
+        const float G = ce * (l + (u ? 1.0f : 0.0f));
+        z[e] = fmaf(y, G - c, (int)list[e] == act ? pol : 0.0f);     // (not y * (pol / y): 0 / 0 when y underflowed to 0)
     }
     ksh_head_wave_sync();
     // dfeat[b] = sum_e dz_e W[list[e]]: lanes own the quads q = lane + 64 i of the row (one 16-byte load per entry and

@@ -498,9 +498,10 @@ ksh_ppo_loss_kernel(KshLossArgs a, const T *__restrict__ logits, T *__restrict__
         const float y = expf(z - m) * inv_s;
         const bool u = (y >= KSH_EPS) && (y <= 1.0f - KSH_EPS);
         const float l = logf(fminf(fmaxf(y, KSH_EPS), 1.0f - KSH_EPS));
-        float G = ce * (l + (u ? 1.0f : 0.0f));
-        if (j == act) G += pol / y;
-        return y * (G - c);
+        // (the taken action's policy term is added as it is, not as y * (pol / y): a probability that underflowed to 0 has
+        // pol = 0 and must give 0, not 0 / 0)
+        const float G = ce * (l + (u ? 1.0f : 0.0f));
+        return fmaf(y, G - c, j == act ? pol : 0.0f);
     };
     if (tid < head) {
         const bool on = !none && ((R.bits[0] >> tid) & 1u);
@@ -701,9 +702,8 @@ ksh_ppo_loss_sparse_kernel(KshLossArgs a, const T *__restrict__ logits, T *__res
         const float y = expf(s_z[wv][e] - m) * inv_s;
         const bool u = (y >= KSH_EPS) && (y <= 1.0f - KSH_EPS);
         const float l = logf(fminf(fmaxf(y, KSH_EPS), 1.0f - KSH_EPS));
-        float G = ce * (l + (u ? 1.0f : 0.0f));
-        if ((int)s_j[wv][e] == act) G += pol / y;
-        s_z[wv][e] = y * (G - c);
+        const float G = ce * (l + (u ? 1.0f : 0.0f));
+        s_z[wv][e] = fmaf(y, G - c, (int)s_j[wv][e] == act ? pol : 0.0f);     // (not y * (pol / y): see the dense kernel)
     }
     constexpr int V = KshVec<T>::N;
     const size_t addr = reinterpret_cast<size_t>(drow);

@@ -50,10 +50,10 @@ def check_head_loss_golden(ops, cases=None):
         np.testing.assert_allclose(dfeat, want_dfeat, rtol=2e-5, atol=2e-6, err_msg=str(ci))
 
 
-def random_head_inputs(B, K, seed, dense_rows=0, empty_rows=0):
+def random_head_inputs(B, K, seed, dense_rows=0, empty_rows=0, w_scale=1.0):
     rng = np.random.default_rng(seed)
     feat = rng.normal(0, 1.0, (B, K)).astype(np.float32)
-    W = rng.normal(0, 2.0 / np.sqrt(K), (A, K)).astype(np.float32)
+    W = rng.normal(0, w_scale * 2.0 / np.sqrt(K), (A, K)).astype(np.float32)
     bias = rng.normal(0, 0.5, A).astype(np.float32)
     _, mask, actions, old_logp, adv, ret, values, old_values = ppocheck.random_loss_inputs(B, seed, dense_rows, empty_rows)
     return feat, W, bias, mask, actions, old_logp, adv, ret, values, old_values
@@ -68,10 +68,19 @@ def head_reference(feat, W, bias, mask, actions, old_logp, adv, ret, values, old
     return st, dz @ f64(W), dz.T @ f64(feat), dz.sum(0), dv, logits
 
 
-def check_head_loss_vs_oracle(ops, B, K, seed, value_clip=0, dense_rows=0, empty_rows=0, dense=True, with_bias=True):
-    feat, W, bias, mask, actions, old_logp, adv, ret, values, old_values = random_head_inputs(B, K, seed, dense_rows, empty_rows)
+def check_head_loss_vs_oracle(ops, B, K, seed, value_clip=0, dense_rows=0, empty_rows=0, dense=True, with_bias=True, w_scale=1.0,
+                              greedy_actions=False):
+    """w_scale > 1 makes the soft-max peaked: probabilities beyond the Categorical eps clamp on both sides (the entries the
+    one-pass input gradient corrects separately); greedy_actions: every other row takes its arg-max action (probability
+    above 1 - eps, no policy gradient)"""
+    feat, W, bias, mask, actions, old_logp, adv, ret, values, old_values = random_head_inputs(B, K, seed, dense_rows, empty_rows,
+                                                                                              w_scale)
     if not with_bias:
         bias = None
+    if greedy_actions:
+        lg = np.where(mask.astype(bool), feat.astype(np.float64) @ W.astype(np.float64).T + (0.0 if bias is None else bias), -np.inf)
+        actions = actions.copy()
+        actions[::2] = lg.argmax(1)[::2]
     dfeat, dW, dbias, dv, st = ops.head_loss(feat, W, bias, mask, actions, old_logp, adv, ret, values, old_values, 0.2, 0.5, 0.01,
                                              value_clip, dense=dense)
     ost, odfeat, odW, odb, odv, _ = head_reference(feat, W, bias, mask, actions, old_logp, adv, ret, values, old_values, 0.2, 0.5,

@@ -101,8 +101,11 @@ def random_loss_inputs(B, seed, dense_rows=0, empty_rows=0):
     return logits, mask, actions, f(1.0) - 3.0, f(1.0), f(1.0), f(1.0), f(1.0)
 
 
-def check_loss_vs_oracle(ops, B, seed, value_clip=0, bf16=False, dense_rows=0, empty_rows=0):
+def check_loss_vs_oracle(ops, B, seed, value_clip=0, bf16=False, dense_rows=0, empty_rows=0, logit_scale=1.0):
+    """logit_scale >> 1: peaked soft-max -- probabilities outside the Categorical eps clamp on both sides, and taken actions
+    whose float32 probability underflows to exactly 0 (gradient 0, not 0 / 0)"""
     logits, mask, actions, old_logp, adv, ret, values, old_values = random_loss_inputs(B, seed, dense_rows, empty_rows)
+    logits = (logits * np.float32(logit_scale)).astype(np.float32)
     if bf16:
         from tests.emu.emu import from_bf16_bits, to_bf16_bits
         logits = from_bf16_bits(to_bf16_bits(logits))      # the oracle sees the same rounded logits

@@ -30,6 +30,13 @@ def test_emu_head_loss_vs_oracle(B, K, vc, dense, empty):
     headcheck.check_head_loss_vs_oracle(ops, B, K, seed=B + K, value_clip=vc, dense_rows=dense, empty_rows=empty)
 
 
+@pytest.mark.parametrize("scale,greedy", [(6.0, False), (25.0, True)])
+def test_emu_head_loss_peaked_softmax_clamped_entries(scale, greedy):
+    """probabilities below eps and above 1 - eps: the entries the one-pass input gradient (K <= 192) fetches a second time"""
+    headcheck.check_head_loss_vs_oracle(ops, 9, 162, seed=21, dense=False, w_scale=scale, greedy_actions=greedy)
+    headcheck.check_head_loss_vs_oracle(ops, 5, 10, seed=22, dense=False, w_scale=scale * 4, greedy_actions=greedy)
+
+
 def test_emu_head_loss_heavy_actions_split_into_segments_and_no_bias():
     """the weight-gradient pipeline with every action that is legal in more than one sample treated as heavy: its bit row
     (B = 70: three dwords, ragged tail) is split into three one-dword segments whose partial rows the combine kernel adds

@@ -34,6 +34,13 @@ def test_gpu_head_loss_sparse_only_and_no_bias(ops):
     headcheck.check_head_loss_vs_oracle(ops, 300, 162, seed=5, dense=False, with_bias=False)
 
 
+@pytest.mark.parametrize("K,scale,greedy", [(162, 6.0, False), (162, 25.0, True), (1296, 25.0, True), (10, 100.0, False)])
+def test_gpu_head_loss_peaked_softmax_clamped_entries(ops, K, scale, greedy):
+    """probabilities below eps / above 1 - eps (the entries the one-pass input gradient of K <= 192 fetches a second time),
+    down to float32 probabilities of exactly 0 for the taken action (gradient 0, not 0 / 0)"""
+    headcheck.check_head_loss_vs_oracle(ops, 70, K, seed=21, dense=False, w_scale=scale, greedy_actions=greedy)
+
+
 def test_gpu_head_dense_row_without_dense_path_is_loud(ops):
     headcheck.check_head_dense_row_without_dense_path_is_loud(ops)
 

@@ -2,8 +2,9 @@
 # build/diag/ (made in the container by substituting one constant each; see profiles/r02_head_kernels_pmc.txt).
 R=$GRAFT_REPO_ROOT
 cd $R
+true
 python tools/headdiag.py 2>/dev/null | tail -1
-for v in branchy t2 t8 t16 u2 u8 na1 na3; do
+for v in ${VARIANTS:-accna3 accna2}; do
     SHOGIDRL_AMD_LIB=$R/build/diag/lib_$v.so python tools/headdiag.py 2>/dev/null | tail -1 || exit 1
 done
 python tools/headdiag.py 2>/dev/null | tail -1
