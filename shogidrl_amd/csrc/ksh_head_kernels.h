@@ -51,7 +51,7 @@ struct KshHeadArgs {
     int want_grad;              // 0: evaluate only (log-prob / entropy / loss terms), nothing below is touched
     float *dfeat;               // [B][K]
     float *dzT;                 // [A][B] scratch: d loss / d logit, transposed, only legal entries are ever written
-    uint32_t *bitsT;            // [A][BW] transposed legal bit matrix (BW = ceil(B/32)), zeroed by the caller
+    uint32_t *bitsT;            // [A][BW] transposed legal bit matrix (BW = ceil(B/32)): written by ksh_head_bits_transpose_kernel
     int BW;
     unsigned *n_over;           // counter of rows left to the dense path
 };
@@ -424,11 +424,63 @@ __global__ void __launch_bounds__(64 * KSH_HEAD_WPB) ksh_head_loss_kernel(KshHea
             if (q < nq) drow[2 * q + 1] = make_float2(acc[i].z, acc[i].w);
         }
     }
-    // transposed scatter for the weight gradient: dzT[a][b], bit b of bitsT row a
-    for (int e = lane; e < n; e += 64) {
-        const int j = (int)list[e];
-        a.dzT[(size_t)j * (size_t)a.B + (size_t)b] = z[e];
-        atomicOr(&a.bitsT[(size_t)j * (size_t)a.BW + (size_t)(b >> 5)], 1u << (b & 31));
+    // transposed scatter for the weight gradient: dzT[a][b].  (The transposed BIT matrix, which tells the weight-gradient
+    // kernels where to look, is built by ksh_head_bits_transpose_kernel from the packed masks: setting bit b of row a from
+    // here took one device-scope atomicOr per legal pair, 152 k of them per minibatch = 19 of this kernel's 44 us.)
+    for (int e = lane; e < n; e += 64) a.dzT[(size_t)list[e] * (size_t)a.B + (size_t)b] = z[e];
+}
+
+// ------------------------------------------------------------------------------------------ transposed bit matrix
+// bitsT[a][w] bit i = action a is legal in sample 32 w + i = bit a of the packed mask row of that sample, for the rows the
+// sparse path handled (rows flagged dense are left out: the MFMA path owns them).  A bit-matrix transpose through LDS:
+// a block takes 512 samples x 512 actions, reads its 64-byte row segments of the packed masks, ORs the (few: 0.3 % are
+// set) bits into a 512 x 16-word LDS tile with LDS atomics and writes the tile's rows as 64-byte segments -- zeros
+// included, so the matrix needs no memset.  Grid: (ceil(BW / 16), ceil(424 / 16)).
+#define KSH_BT_TS 16       // sample words (of 32 samples) per tile
+#define KSH_BT_TA 16       // action words (of 32 actions) per tile
+#define KSH_BT_THREADS 1024
+extern "C" __global__ void __launch_bounds__(KSH_BT_THREADS) ksh_head_bits_transpose_kernel(
+    const uint32_t *__restrict__ mask_bits, const float *__restrict__ flags, int B, int BW, uint32_t *__restrict__ bitsT) {
+    __shared__ uint32_t T[32 * KSH_BT_TA][KSH_BT_TS + 1];
+    __shared__ float s_flag[32 * KSH_BT_TS];
+    const int t = (int)threadIdx.x;
+    const int w0 = (int)blockIdx.x * KSH_BT_TS, c0 = (int)blockIdx.y * KSH_BT_TA;
+    constexpr int NW = 32 * KSH_BT_TS * KSH_BT_TA;       // words of the input tile: 512 samples x 16
+    constexpr int PER = NW / KSH_BT_THREADS;             // 8 independent loads per thread
+    uint32_t v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int u = t + KSH_BT_THREADS * i;
+        const int sl = u >> 4, c = c0 + (u & 15);
+        const int b = 32 * w0 + sl;
+        const bool in = b < B && c < KSH_PBITROW;
+        uint32_t x = mask_bits[(size_t)(in ? b : 0) * KSH_PBITROW + (size_t)(in ? c : 0)];
+        x = c < 422 ? x : (c == 422 ? (x & 0x007FFFFFu) : 0u);      // bits >= 13527 never count
+        v[i] = in ? x : 0u;
+    }
+    if (t < 32 * KSH_BT_TS) s_flag[t] = 32 * w0 + t < B ? flags[(size_t)(32 * w0 + t) * 8] : 0.0f;
+    for (int i = t; i < 32 * KSH_BT_TA * (KSH_BT_TS + 1); i += KSH_BT_THREADS) (&T[0][0])[i] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        uint32_t x = v[i];
+        const int u = t + KSH_BT_THREADS * i;
+        const int sl = u >> 4, cw = u & 15;
+        if (x == 0u || s_flag[sl] != 0.0f) continue;               // nothing legal here / a dense row: not ours
+        const uint32_t bit = 1u << (sl & 31);
+        while (x) {
+            const int k = __ffs((int)x) - 1;
+            x &= x - 1u;
+            atomicOr(&T[32 * cw + k][sl >> 5], bit);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int u = t + KSH_BT_THREADS * i;
+        const int jl = u >> 4, k = u & 15;
+        const int j = 32 * c0 + jl, w = w0 + k;
+        if (j < KSH_PA && w < BW) bitsT[(size_t)j * (size_t)BW + (size_t)w] = T[jl][k];
     }
 }
 

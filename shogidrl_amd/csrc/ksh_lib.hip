@@ -419,7 +419,7 @@ static HeadWs head_ws(void *workspace, int B, int K, int dense) {
     char *p = (char *)workspace;
     w.partial = (float *)p;
     p += head_align((size_t)B * 32 + 64);
-    w.n_over = (unsigned *)p;                 // the two counters sit right in front of the bit matrix: ONE memset zeroes all three
+    w.n_over = (unsigned *)p;                 // 256 bytes of counters / flags, zeroed by one small memset per call
     w.n_items = w.n_over + 1;
     p += 256;
     w.BW = (B + 31) / 32;
@@ -514,8 +514,8 @@ static int head_loss_impl(const float *feat, const float *W, const float *bias, 
     L.overflow_is_error = dense ? 0 : 1;
     a.want_grad = want_grad;
     a.dfeat = dfeat; a.dzT = w.dzT; a.bitsT = w.bitsT; a.BW = w.BW; a.n_over = w.n_over;
-    // the dense-row counter and (for the backward) the transposed bit matrix start from zero
-    HIP_TRY(hipMemsetAsync(w.n_over, 0, want_grad ? 256 + (size_t)KSH_PA * w.BW * 4 : 256, st));
+    // the dense-row counter, the work-list length and its "corrupt" flag start from zero
+    HIP_TRY(hipMemsetAsync(w.n_over, 0, 256, st));
     const dim3 grid((B + KSH_HEAD_WPB - 1) / KSH_HEAD_WPB), block(64 * KSH_HEAD_WPB);
     if (K <= 192) hipLaunchKernelGGL(ksh_head_loss_kernel<192>, grid, block, 0, st, a);
     else hipLaunchKernelGGL(ksh_head_loss_kernel<1312>, grid, block, 0, st, a);
@@ -536,6 +536,9 @@ static int head_loss_impl(const float *feat, const float *W, const float *bias, 
                            want_grad ? w.dlbuf : (float *)nullptr);
     }
     if (want_grad) {
+        // where each action was legal: the packed masks transposed (rows the loss kernel flagged as dense left out)
+        hipLaunchKernelGGL(ksh_head_bits_transpose_kernel, dim3((w.BW + KSH_BT_TS - 1) / KSH_BT_TS, (KSH_PBITROW + KSH_BT_TA - 1) / KSH_BT_TA),
+                           dim3(KSH_BT_THREADS), 0, st, mask_bits, (const float *)(w.partial + 6), B, w.BW, w.bitsT);
         KshHeadDwArgs d;
         d.feat = feat; d.dzT = w.dzT; d.bitsT = w.bitsT; d.dW = dW; d.dbias = dbias;
         d.B = B; d.BW = w.BW; d.K = K; d.A = KSH_PA;
