@@ -30,7 +30,7 @@ def test_gpu_ppo_loss_vs_oracle(ops, B, vc, dense, empty):
     ppocheck.check_loss_vs_oracle(ops, B, seed=B, value_clip=vc, dense_rows=dense, empty_rows=empty)
 
 
-def test_gpu_ppo_loss_peaked_softmax_underflowing_probabilities():
+def test_gpu_ppo_loss_peaked_softmax_underflowing_probabilities(ops):
     """logits spread over +-150: taken actions with float32 probability 0 (the gradient used to be y * (pol / y) = 0 / 0),
     one probability above 1 - eps per row"""
     ppocheck.check_loss_vs_oracle(ops, 24, seed=5, logit_scale=40.0, dense_rows=1)
