@@ -435,15 +435,27 @@ __global__ void __launch_bounds__(64 * KSH_HEAD_WPB) ksh_head_loss_kernel(KshHea
 // sparse path handled (rows flagged dense are left out: the MFMA path owns them).  A bit-matrix transpose through LDS:
 // a block takes 512 samples x 512 actions, reads its 64-byte row segments of the packed masks, ORs the (few: 0.3 % are
 // set) bits into a 512 x 16-word LDS tile with LDS atomics and writes the tile's rows as 64-byte segments -- zeros
-// included, so the matrix needs no memset.  Grid: (ceil(BW / 16), ceil(424 / 16)).
+// included, so the matrix needs no memset.  Grid: (ceil(BW / 16), ceil(424 / 16) + 1).
 #define KSH_BT_TS 16       // sample words (of 32 samples) per tile
 #define KSH_BT_TA 16       // action words (of 32 actions) per tile
 #define KSH_BT_THREADS 1024
+// The launch carries one extra row of blocks (blockIdx.y == gridDim.y - 1): its first block zeroes the work-list counters
+// of the weight-gradient kernels and runs the batch statistics (ksh_ppo_stats_body: the loss terms and dvalues only depend
+// on the row kernels before this launch), which saves a memset and a dependent launch of ~5 us each.
+static_assert(KSH_BT_THREADS == KSH_STATS_THREADS, "the statistics block runs inside the transpose launch");
 extern "C" __global__ void __launch_bounds__(KSH_BT_THREADS) ksh_head_bits_transpose_kernel(
-    const uint32_t *__restrict__ mask_bits, const float *__restrict__ flags, int B, int BW, uint32_t *__restrict__ bitsT) {
+    const uint32_t *__restrict__ mask_bits, const float *__restrict__ flags, int B, int BW, uint32_t *__restrict__ bitsT,
+    KshLossArgs L, unsigned *__restrict__ n_items) {
     __shared__ uint32_t T[32 * KSH_BT_TA][KSH_BT_TS + 1];
     __shared__ float s_flag[32 * KSH_BT_TS];
+    __shared__ KshStatsLds s_stats;
     const int t = (int)threadIdx.x;
+    if (blockIdx.y == gridDim.y - 1) {     // block-uniform
+        if (blockIdx.x != 0) return;
+        if (t < 2) n_items[t] = 0u;        // work-list length, "corrupt" flag (the scan kernel is the next launch)
+        ksh_ppo_stats_body(L, s_stats);
+        return;
+    }
     const int w0 = (int)blockIdx.x * KSH_BT_TS, c0 = (int)blockIdx.y * KSH_BT_TA;
     constexpr int NW = 32 * KSH_BT_TS * KSH_BT_TA;       // words of the input tile: 512 samples x 16
     constexpr int PER = NW / KSH_BT_THREADS;             // 8 independent loads per thread

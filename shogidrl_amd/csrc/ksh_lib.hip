@@ -514,8 +514,9 @@ static int head_loss_impl(const float *feat, const float *W, const float *bias, 
     L.overflow_is_error = dense ? 0 : 1;
     a.want_grad = want_grad;
     a.dfeat = dfeat; a.dzT = w.dzT; a.bitsT = w.bitsT; a.BW = w.BW; a.n_over = w.n_over;
-    // the dense-row counter, the work-list length and its "corrupt" flag start from zero
-    HIP_TRY(hipMemsetAsync(w.n_over, 0, 256, st));
+    // the dense-row counter only matters to the dense path's launches (the work-list counters are zeroed by the transpose
+    // launch): without a dense path there is nothing to clear
+    if (dense) HIP_TRY(hipMemsetAsync(w.n_over, 0, 256, st));
     const dim3 grid((B + KSH_HEAD_WPB - 1) / KSH_HEAD_WPB), block(64 * KSH_HEAD_WPB);
     if (K <= 192) hipLaunchKernelGGL(ksh_head_loss_kernel<192>, grid, block, 0, st, a);
     else hipLaunchKernelGGL(ksh_head_loss_kernel<1312>, grid, block, 0, st, a);
@@ -537,8 +538,10 @@ static int head_loss_impl(const float *feat, const float *W, const float *bias, 
     }
     if (want_grad) {
         // where each action was legal: the packed masks transposed (rows the loss kernel flagged as dense left out)
-        hipLaunchKernelGGL(ksh_head_bits_transpose_kernel, dim3((w.BW + KSH_BT_TS - 1) / KSH_BT_TS, (KSH_PBITROW + KSH_BT_TA - 1) / KSH_BT_TA),
-                           dim3(KSH_BT_THREADS), 0, st, mask_bits, (const float *)(w.partial + 6), B, w.BW, w.bitsT);
+        // (+ one row of blocks: work-list counters zeroed, batch statistics -- see the kernel)
+        hipLaunchKernelGGL(ksh_head_bits_transpose_kernel,
+                           dim3((w.BW + KSH_BT_TS - 1) / KSH_BT_TS, (KSH_PBITROW + KSH_BT_TA - 1) / KSH_BT_TA + 1),
+                           dim3(KSH_BT_THREADS), 0, st, mask_bits, (const float *)(w.partial + 6), B, w.BW, w.bitsT, L, w.n_items);
         KshHeadDwArgs d;
         d.feat = feat; d.dzT = w.dzT; d.bitsT = w.bitsT; d.dW = dW; d.dbias = dbias;
         d.B = B; d.BW = w.BW; d.K = K; d.A = KSH_PA;
@@ -581,8 +584,10 @@ static int head_loss_impl(const float *feat, const float *W, const float *bias, 
         }
     }
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(ksh_ppo_stats_kernel, dim3(1), dim3(KSH_STATS_THREADS), 0, st, L);
-    HIP_TRY(hipGetLastError());
+    if (!want_grad) {       // (with gradients the statistics ran inside the transpose launch)
+        hipLaunchKernelGGL(ksh_ppo_stats_kernel, dim3(1), dim3(KSH_STATS_THREADS), 0, st, L);
+        HIP_TRY(hipGetLastError());
+    }
     return KSH_OK;
 }
 

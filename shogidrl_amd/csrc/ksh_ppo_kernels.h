@@ -725,10 +725,17 @@ ksh_ppo_loss_sparse_kernel(KshLossArgs a, const T *__restrict__ logits, T *__res
 // Batch means, the value-loss branch (max of the two MEANS, ppo_agent.py:357-373) and d(loss)/d(values).
 // One block of KSH_STATS_THREADS threads (any power of two up to that works); fixed-order tree reduction.
 #define KSH_STATS_THREADS 1024
-extern "C" __global__ void __launch_bounds__(KSH_STATS_THREADS) ksh_ppo_stats_kernel(KshLossArgs a) {
-    __shared__ float red[KSH_STATS_THREADS][6];
-    __shared__ float tot[6];
-    __shared__ int bad;
+struct KshStatsLds {
+    float red[KSH_STATS_THREADS][6];
+    float tot[6];
+    int bad;
+};
+// the body, for one whole block of blockDim.x (a power of two <= KSH_STATS_THREADS) threads: ksh_ppo_stats_kernel below, and
+// one block of the fused head's bit-matrix transpose launch (ksh_head_kernels.h), which saves a dependent launch
+__device__ __forceinline__ void ksh_ppo_stats_body(const KshLossArgs &a, KshStatsLds &S) {
+    float (*red)[6] = S.red;
+    float *tot = S.tot;
+    int &bad = S.bad;
     const int tid = threadIdx.x, nt = (int)blockDim.x;
     float acc[6] = {0, 0, 0, 0, 0, 0};
     int flagged = 0;
@@ -793,4 +800,9 @@ extern "C" __global__ void __launch_bounds__(KSH_STATS_THREADS) ksh_ppo_stats_ke
         }
         a.dvalues[i] = g;
     }
+}
+
+extern "C" __global__ void __launch_bounds__(KSH_STATS_THREADS) ksh_ppo_stats_kernel(KshLossArgs a) {
+    __shared__ KshStatsLds S;
+    ksh_ppo_stats_body(a, S);
 }
