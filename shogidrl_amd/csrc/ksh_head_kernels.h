@@ -302,7 +302,14 @@ __global__ void __launch_bounds__(64 * KSH_HEAD_WPB) ksh_head_loss_kernel(KshHea
     float *part = L.partial + (size_t)b * 8;
     const int n = ksh_head_collect(a.mask_bits + (size_t)b * KSH_PBITROW, lane, S.list[wv], KSH_HEAD_CAP);
     if (n > KSH_HEAD_CAP) {            // wave-uniform: a dense row, left to the MFMA path
-        if (lane == 0) { part[6] = 1.0f; atomicAdd(a.n_over, 1u); }
+        if (lane == 0) {
+            part[6] = 1.0f;
+            atomicAdd(a.n_over, 1u);
+            if (L.overflow_is_error) {  // ... which the caller said would not be needed: the row's outputs must not look valid
+                if (L.row_logp != nullptr) L.row_logp[b] = NAN;
+                if (L.row_entropy != nullptr) L.row_entropy[b] = NAN;
+            }
+        }
         return;
     }
     unsigned short *list = S.list[wv];

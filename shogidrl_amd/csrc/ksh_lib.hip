@@ -584,10 +584,8 @@ static int head_loss_impl(const float *feat, const float *W, const float *bias, 
         }
     }
     HIP_TRY(hipGetLastError());
-    if (!want_grad) {       // (with gradients the statistics ran inside the transpose launch)
-        hipLaunchKernelGGL(ksh_ppo_stats_kernel, dim3(1), dim3(KSH_STATS_THREADS), 0, st, L);
-        HIP_TRY(hipGetLastError());
-    }
+    // (with gradients the batch statistics ran inside the transpose launch; the evaluate-only call has per-row outputs
+    // only -- a dense row met without a dense path gets NaN there from the row kernel -- and needs none)
     return KSH_OK;
 }
 

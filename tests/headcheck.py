@@ -102,6 +102,8 @@ def check_head_dense_row_without_dense_path_is_loud(ops):
     _, _, _, dv, st = ops.head_loss(feat, W, bias, mask, actions, old_logp, adv, ret, values, old_values, 0.2, 0.5, 0.01, 0,
                                     dense=False)
     assert np.isnan(st[:6]).all() and np.isnan(dv).all()
+    lp, en = ops.head_evaluate(feat, W, bias, mask, actions, dense=False)      # evaluate-only: the dense row's outputs are NaN
+    assert np.isnan(lp[0]) and np.isnan(en[0]) and np.isfinite(lp[1:]).all() and np.isfinite(en[1:]).all()
 
 
 def check_head_evaluate(ops, B=7, K=162, seed=12):

@@ -71,6 +71,10 @@ def test_emu_head_corrupt_work_list_is_contained_and_poisons_the_gradient(mode):
     assert np.isnan(dW[0]).all() and np.isnan(dbias[0])
 
 
+def test_emu_head_dense_row_without_dense_path_is_loud():
+    headcheck.check_head_dense_row_without_dense_path_is_loud(ops)
+
+
 def test_emu_head_evaluate():
     headcheck.check_head_evaluate(ops)
 
