@@ -165,6 +165,39 @@ def minibatch64_rate(agent, buf, dev, updates=64, note=lambda msg: None):
     return out
 
 
+def fused_head_times(agent, buf, dev, reps=20):
+    """Device time of the fused policy head on one real minibatch of the rollout buffer: sampler, and loss
+    forward + backward (all of its kernels: row kernel, bit-matrix transpose + statistics, scan / work / combine), between
+    hipEvents on the launch stream, after the timed region."""
+    from shogidrl_amd import ops
+    from shogidrl_amd.env import DeviceTimer
+    if not getattr(agent, "fused_head", False):
+        return None
+    n = buf.N
+    with torch.no_grad():
+        agent.model.train()
+        feat, values = agent._features(buf.obs[0])
+    lin = agent.model.policy_linear
+    W, b = lin.weight.detach(), (None if lin.bias is None else lin.bias.detach())
+    bits, act = buf.legal_bits[0], buf.actions[0]
+    lp, adv, ret = buf.log_probs[0], buf.advantages[0], buf.returns[0]
+    tm = DeviceTimer()
+    out = {"rows": int(n), "K": int(feat.shape[1]),
+           "mean_legal_actions": float(ops.unpack_mask(bits).float().sum(1).mean())}
+    for name, fn in (("sample_us", lambda: ops.policy_head_sample(feat, W, b, bits, 7, 0)),
+                     ("loss_fwd_bwd_us", lambda: ops.policy_head_loss_grads(feat, W, b, values, bits, act, lp, adv, ret, None, 0.2,
+                                                                            0.5, 0.01, False, dense_rows_possible=False))):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        tm.start()
+        for _ in range(reps):
+            fn()
+        tm.stop()
+        out[name] = round(tm.elapsed_ms() / reps * 1e3, 1)
+    return out
+
+
 def env_roofline(dev, n_games, replay_steps, seed):
     """Average device time of ksh_env_step_kernel from `replay_steps` back-to-back launches between two
     hipEvents on the launch stream: a recorded self-play action stream is replayed on a second env."""
@@ -398,6 +431,10 @@ def main():
             "ppo_metrics": metrics,
             "episodes": runner.episode_stats(),
         }
+        try:
+            out["fused_policy_head"] = fused_head_times(agent, buf, dev)
+        except Exception as e:                   # a side figure: never let it take the headline measurement down
+            out["fused_policy_head"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             out["ppo_reference_minibatch64"] = minibatch64_rate(agent, buf, dev, note=note)
             torch.cuda.synchronize()
