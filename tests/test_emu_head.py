@@ -30,11 +30,11 @@ def test_emu_head_loss_vs_oracle(B, K, vc, dense, empty):
     headcheck.check_head_loss_vs_oracle(ops, B, K, seed=B + K, value_clip=vc, dense_rows=dense, empty_rows=empty)
 
 
-@pytest.mark.parametrize("scale,greedy", [(6.0, False), (25.0, True)])
-def test_emu_head_loss_peaked_softmax_clamped_entries(scale, greedy):
-    """probabilities below eps and above 1 - eps: the entries the one-pass input gradient (K <= 192) fetches a second time"""
-    headcheck.check_head_loss_vs_oracle(ops, 9, 162, seed=21, dense=False, w_scale=scale, greedy_actions=greedy)
-    headcheck.check_head_loss_vs_oracle(ops, 5, 10, seed=22, dense=False, w_scale=scale * 4, greedy_actions=greedy)
+def test_emu_head_loss_peaked_softmax_clamped_entries():
+    """probabilities below eps and above 1 - eps, down to float32 probabilities of exactly 0 for the taken action (gradient
+    0, not 0 / 0); the GPU suite runs more sizes"""
+    headcheck.check_head_loss_vs_oracle(ops, 9, 162, seed=21, dense=False, w_scale=25.0, greedy_actions=True)
+    headcheck.check_head_loss_vs_oracle(ops, 5, 10, seed=22, dense=False, w_scale=24.0, greedy_actions=False)
 
 
 def test_emu_head_loss_heavy_actions_split_into_segments_and_no_bias():
