@@ -393,11 +393,58 @@ __global__ void __launch_bounds__(64 * KSH_HEAD_WPB) ksh_head_loss_kernel(KshHea
         z[e] = fmaf(y, G - c, (int)list[e] == act ? pol : 0.0f);     // (not y * (pol / y): 0 / 0 when y underflowed to 0)
     }
     ksh_head_wave_sync();
-    // dfeat[b] = sum_e dz_e W[list[e]]: lanes own the quads q = lane + 64 i of the row (one 16-byte load per entry and
-    // lane for K = 162), U entries' loads in flight at once
-    {
+    // dfeat[b] = sum_e dz_e W[list[e]].  K <= 192: four 16-lane groups take every fourth entry (lane s of a group owns quads
+    // s, s+16, s+32 of the row), 16 rows in flight per round -- a row with 48 legal actions is three rounds, where one
+    // entry per load instruction (lane = quad, U in flight) was twelve; the groups' sums are added in a fixed order.
+    if constexpr (KMAX <= 192) {
+        constexpr int U = 4;
+        const int gs = lane & 15, gg = lane >> 4;
+        const int nq = a.K >> 2;
+        const bool tail = (a.K & 2) != 0;
+        float4 acc[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) acc[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int e0 = 0; e0 < n; e0 += 4 * U) {      // wave-uniform trip count
+            float4 w[U][3];
+            float dz[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int e = e0 + 4 * u + gg;
+                dz[u] = e < n ? z[e] : 0.0f;
+                const float *wrow = a.W + (size_t)list[e < n ? e : 0] * (size_t)a.K;
+#pragma unroll
+                for (int i = 0; i < 3; i++) w[u][i] = ksh_ld_quad(wrow, gs + 16 * i, nq, tail);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    acc[i].x = fmaf(dz[u], w[u][i].x, acc[i].x); acc[i].y = fmaf(dz[u], w[u][i].y, acc[i].y);
+                    acc[i].z = fmaf(dz[u], w[u][i].z, acc[i].z); acc[i].w = fmaf(dz[u], w[u][i].w, acc[i].w);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                acc[i].x += __shfl_xor(acc[i].x, o); acc[i].y += __shfl_xor(acc[i].y, o);
+                acc[i].z += __shfl_xor(acc[i].z, o); acc[i].w += __shfl_xor(acc[i].w, o);
+            }
+        }
+        float2 *drow = reinterpret_cast<float2 *>(a.dfeat + (size_t)b * (size_t)a.K);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int q = gs + 16 * i;
+            if (gg == i) {
+                if (q < nq || (q == nq && tail)) drow[2 * q] = make_float2(acc[i].x, acc[i].y);
+                if (q < nq) drow[2 * q + 1] = make_float2(acc[i].z, acc[i].w);
+            }
+        }
+    } else {
+        // wider rows: lanes own the quads q = lane + 64 i of the row, U entries' loads in flight at once
         constexpr int QQ = (KMAX / 4 + 63) / 64;
-        constexpr int U = QQ == 1 ? 4 : 2;      // (8 / 12 / 16 in flight measured no faster: profiles/r02_head_kernels_pmc.txt)
+        constexpr int U = 2;
         const int nq = a.K >> 2;
         const bool tail = (a.K & 2) != 0;
         float4 acc[QQ];
@@ -610,6 +657,8 @@ template <int KMAX>
 __global__ void __launch_bounds__(64 * KSH_DW_WPB) ksh_head_dw_work_kernel(KshHeadDwArgs a) {
     constexpr int QQ = (KMAX / 4 + 63) / 64;
     constexpr int T = QQ == 1 ? 4 : 2;      // (2 / 8 / 16 in flight measured slower: profiles/r02_head_kernels_pmc.txt)
+    constexpr bool GROUPED = KMAX <= 192;   // 16 lanes x 3 quads cover a feature row: four samples side by side
+    const int gs = (int)(threadIdx.x & 15), gg = (int)((threadIdx.x & 63) >> 4);
     __shared__ int s_rows[KSH_DW_WPB][KSH_DW_WIN];
     __shared__ float s_dz[KSH_DW_WPB][KSH_DW_WIN];
     const int lane = threadIdx.x & 63;
@@ -642,6 +691,9 @@ __global__ void __launch_bounds__(64 * KSH_DW_WPB) ksh_head_dw_work_kernel(KshHe
         float4 acc[QQ];
 #pragma unroll
         for (int i = 0; i < QQ; i++) acc[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float4 ag[3];              // GROUPED: this lane's quads gs, gs + 16, gs + 32 of its group's partial row
+#pragma unroll
+        for (int i = 0; i < 3; i++) ag[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         float dzsum = 0.0f;
         for (int c0 = d0; c0 < d1; c0 += 64) {
             // lane = dword of the bit row; an inclusive scan of the popcounts ranks every legal sample of the chunk
@@ -670,6 +722,35 @@ __global__ void __launch_bounds__(64 * KSH_DW_WPB) ksh_head_dw_work_kernel(KshHe
                 const int cw = total - w0 < KSH_DW_WIN ? total - w0 : KSH_DW_WIN;
                 for (int i = lane; i < cw; i += 64) dzl[i] = zrow[rows[i]];   // all of the window's dz loads in flight at once
                 ksh_head_wave_sync();
+                if constexpr (GROUPED) {
+                    // four 16-lane groups take every fourth sample of the window: 4 T rows in flight per round, a quarter
+                    // of the rounds (an item's time is its chain of rounds: a 256-sample segment is 16 of them, not 64)
+                    for (int e0 = 0; e0 < cw; e0 += 4 * T) {
+                        float4 f[T][3];
+                        float dz[T];
+                        bool on[T];
+#pragma unroll
+                        for (int t = 0; t < T; t++) {
+                            const int e = e0 + 4 * t + gg;
+                            on[t] = e < cw;
+                            dz[t] = on[t] ? dzl[e] : 0.0f;
+                            const float *frow = a.feat + (size_t)rows[on[t] ? e : e0] * (size_t)a.K;
+#pragma unroll
+                            for (int i = 0; i < 3; i++) f[t][i] = ksh_ld_quad(frow, gs + 16 * i, nq, tail);
+                        }
+#pragma unroll
+                        for (int t = 0; t < T; t++) {
+                            if (on[t]) {                             // (no "+ 0 * x" terms in the sums)
+                                dzsum += dz[t];
+#pragma unroll
+                                for (int i = 0; i < 3; i++) {
+                                    ag[i].x = fmaf(dz[t], f[t][i].x, ag[i].x); ag[i].y = fmaf(dz[t], f[t][i].y, ag[i].y);
+                                    ag[i].z = fmaf(dz[t], f[t][i].z, ag[i].z); ag[i].w = fmaf(dz[t], f[t][i].w, ag[i].w);
+                                }
+                            }
+                        }
+                    }
+                } else
                 for (int e0 = 0; e0 < cw; e0 += T) {              // feature rows: T in flight, added in ascending order
                     float4 f[T][QQ];
                     float dz[T];
@@ -698,11 +779,32 @@ __global__ void __launch_bounds__(64 * KSH_DW_WPB) ksh_head_dw_work_kernel(KshHe
         }
         // a light action is complete: straight into the gradient; a segment of a heavy one: partial row for the combine kernel
         float2 *prow = reinterpret_cast<float2 *>(whole ? a.dW + (size_t)j * (size_t)a.K : a.partial + (size_t)it * (size_t)a.K);
+        if constexpr (GROUPED) {
+            // the four groups' sums ((g0 + g1) + (g2 + g3): a fixed order); group i then stores quad gs + 16 i
 #pragma unroll
-        for (int i = 0; i < QQ; i++) {
-            const int q = lane + 64 * i;
-            if (q < nq || (q == nq && tail)) prow[2 * q] = make_float2(acc[i].x, acc[i].y);
-            if (q < nq) prow[2 * q + 1] = make_float2(acc[i].z, acc[i].w);
+            for (int o = 16; o <= 32; o <<= 1) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    ag[i].x += __shfl_xor(ag[i].x, o); ag[i].y += __shfl_xor(ag[i].y, o);
+                    ag[i].z += __shfl_xor(ag[i].z, o); ag[i].w += __shfl_xor(ag[i].w, o);
+                }
+                dzsum += __shfl_xor(dzsum, o);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const int q = gs + 16 * i;
+                if (gg == i) {
+                    if (q < nq || (q == nq && tail)) prow[2 * q] = make_float2(ag[i].x, ag[i].y);
+                    if (q < nq) prow[2 * q + 1] = make_float2(ag[i].z, ag[i].w);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < QQ; i++) {
+                const int q = lane + 64 * i;
+                if (q < nq || (q == nq && tail)) prow[2 * q] = make_float2(acc[i].x, acc[i].y);
+                if (q < nq) prow[2 * q + 1] = make_float2(acc[i].z, acc[i].w);
+            }
         }
         if (lane == 0) {
             if (!whole) a.partial_dz[it] = dzsum;
