@@ -656,7 +656,7 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_DW_SCAN_WPB) ksh_head_dw_s
 template <int KMAX>
 __global__ void __launch_bounds__(64 * KSH_DW_WPB) ksh_head_dw_work_kernel(KshHeadDwArgs a) {
     constexpr int QQ = (KMAX / 4 + 63) / 64;
-    constexpr int T = QQ == 1 ? 4 : 2;      // (2 / 8 / 16 in flight measured slower: profiles/r02_head_kernels_pmc.txt)
+    constexpr int T = 2;                    // rows in flight per group and round (4 / 8 measured slower: profiles/r02_head_kernels_pmc.txt)
     constexpr bool GROUPED = KMAX <= 192;   // 16 lanes x 3 quads cover a feature row: four samples side by side
     const int gs = (int)(threadIdx.x & 15), gg = (int)((threadIdx.x & 63) >> 4);
     __shared__ int s_rows[KSH_DW_WPB][KSH_DW_WIN];
