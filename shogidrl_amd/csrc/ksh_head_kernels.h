@@ -201,6 +201,25 @@ __device__ __forceinline__ void ksh_head_stage_feat(const KshHeadArgs &a, int b,
     for (int p = lane; p < ((np + 1) & ~1); p += 64) d2[p] = p < np ? src[p] : make_float2(0.0f, 0.0f);   // padded to a quad
     ksh_head_wave_sync();
 }
+// K <= 192 (at most 96 pairs: two per lane): the feature row is FETCHED at the top of the kernel, next to the mask row, and
+// only written to LDS after the id list has been built -- one global round trip on the wave's critical path instead of two
+struct KshFeatRegs { float2 r0, r1; };
+__device__ __forceinline__ KshFeatRegs ksh_head_fetch_feat(const KshHeadArgs &a, int b, int lane) {
+    const float2 *src = reinterpret_cast<const float2 *>(a.feat + (size_t)b * (size_t)a.K);
+    const int np = a.K >> 1;
+    KshFeatRegs f;
+    const float2 x0 = src[lane < np ? lane : 0], x1 = src[lane + 64 < np ? lane + 64 : 0];      // unconditional (clamped) loads
+    f.r0 = lane < np ? x0 : make_float2(0.0f, 0.0f);
+    f.r1 = lane + 64 < np ? x1 : make_float2(0.0f, 0.0f);
+    return f;
+}
+__device__ __forceinline__ void ksh_head_put_feat(const KshHeadArgs &a, const KshFeatRegs &f, int lane, float *dst) {
+    float2 *d2 = reinterpret_cast<float2 *>(dst);
+    const int np2 = ((a.K >> 1) + 1) & ~1;                    // padded to a quad
+    if (lane < np2) d2[lane] = f.r0;
+    if (lane + 64 < np2) d2[lane + 64] = f.r1;
+    ksh_head_wave_sync();
+}
 
 // ------------------------------------------------------------------------------------------ fused head + sampler
 // get_action_and_value's tail without logits in memory: gather-dot of the legal rows of W, Gumbel-max sample (or
@@ -217,9 +236,12 @@ __global__ void __launch_bounds__(64 * KSH_HEAD_WPB) ksh_head_sample_kernel(KshH
     const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32), s0 = (uint32_t)step, s1 = (uint32_t)(step >> 32);
     const bool det = a.deterministic != 0;
     const uint32_t *brow = a.mask_bits + (size_t)b * KSH_PBITROW;
+    KshFeatRegs fr;
+    if constexpr (KMAX <= 192) fr = ksh_head_fetch_feat(a, b, lane);
     const int total = ksh_head_collect(brow, lane, S.list[wv], KSH_HEAD_CAP);
     const int n = total < KSH_HEAD_CAP ? total : KSH_HEAD_CAP;
-    ksh_head_stage_feat<KMAX>(a, b, lane, S.feat[wv]);
+    if constexpr (KMAX <= 192) ksh_head_put_feat(a, fr, lane, S.feat[wv]);
+    else ksh_head_stage_feat<KMAX>(a, b, lane, S.feat[wv]);
     ksh_head_logits<KMAX>(a, S.feat[wv], S.list[wv], n, lane, S.z[wv]);
     KshSampleAcc A = {-INFINITY, 0.0f, -INFINITY, 0.0f, -1};
     auto visit = [&](int j, float z) {
@@ -300,6 +322,13 @@ __global__ void __launch_bounds__(64 * KSH_HEAD_WPB) ksh_head_loss_kernel(KshHea
     if (b >= a.B) return;  // wave-uniform
     const KshLossArgs &L = a.L;
     float *part = L.partial + (size_t)b * 8;
+    // every global input of this row is requested up front (the loads would otherwise sit, one round trip each, behind the
+    // fences of the phases that need them)
+    KshFeatRegs fr;
+    if constexpr (KMAX <= 192) fr = ksh_head_fetch_feat(a, b, lane);
+    const int act = (int)L.actions[b];
+    const float old_lp = L.old_logp[b], Adv = L.adv[b], Vin = L.values[b], Rt = L.ret[b];
+    const float ov_in = L.value_clip ? L.old_values[b] : 0.0f;
     const int n = ksh_head_collect(a.mask_bits + (size_t)b * KSH_PBITROW, lane, S.list[wv], KSH_HEAD_CAP);
     if (n > KSH_HEAD_CAP) {            // wave-uniform: a dense row, left to the MFMA path
         if (lane == 0) {
@@ -314,7 +343,8 @@ __global__ void __launch_bounds__(64 * KSH_HEAD_WPB) ksh_head_loss_kernel(KshHea
     }
     unsigned short *list = S.list[wv];
     float *z = S.z[wv];
-    ksh_head_stage_feat<KMAX>(a, b, lane, S.feat[wv]);
+    if constexpr (KMAX <= 192) ksh_head_put_feat(a, fr, lane, S.feat[wv]);
+    else ksh_head_stage_feat<KMAX>(a, b, lane, S.feat[wv]);
     ksh_head_logits<KMAX>(a, S.feat[wv], list, n, lane, z);
     // pass 1: soft-max statistics
     float m = -INFINITY, s = 0.0f;
@@ -326,7 +356,6 @@ __global__ void __launch_bounds__(64 * KSH_HEAD_WPB) ksh_head_loss_kernel(KshHea
     }
     const bool none = n == 0;
     const float inv_s = none ? 0.0f : 1.0f / s;
-    const int act = (int)L.actions[b];
     const float invB = 1.0f / (float)L.B;
     // pass 2: entropy terms and the taken action's probability
     float e1 = 0.0f, e2 = 0.0f, ya = 0.0f;
@@ -356,7 +385,6 @@ __global__ void __launch_bounds__(64 * KSH_HEAD_WPB) ksh_head_loss_kernel(KshHea
         new_logp = logf(fminf(fmaxf(ya, KSH_EPS), 1.0f - KSH_EPS));
         H = -e1;
     }
-    const float old_lp = L.old_logp[b], Adv = L.adv[b];
     const float ratio = expf(new_logp - old_lp);
     const float surr1 = ratio * Adv;
     const float surr2 = fminf(fmaxf(ratio, 1.0f - L.clip_eps), 1.0f + L.clip_eps) * Adv;
@@ -365,12 +393,12 @@ __global__ void __launch_bounds__(64 * KSH_HEAD_WPB) ksh_head_loss_kernel(KshHea
     const float ce = L.ent_coef * invB;
     const float c = ce * (e1 + e2) + pol;
     if (lane == 0) {
-        const float V = L.values[b], Rt = L.ret[b];
+        const float V = Vin;
         part[0] = fminf(surr1, surr2);
         part[1] = (V - Rt) * (V - Rt);
         float vc = 0.0f;
         if (L.value_clip) {
-            const float ov = L.old_values[b];
+            const float ov = ov_in;
             const float Vc = ov + fminf(fmaxf(V - ov, -L.clip_eps), L.clip_eps);
             vc = (Vc - Rt) * (Vc - Rt);
         }
