@@ -408,7 +408,6 @@ class VecPPOAgent(_Acting):
     def load_model(self, file_path):
         """Returns the reference's result dict; a missing / broken file yields zeros and an "error" entry
         (ppo_agent.py:489-537) instead of raising.  Files are read with weights_only=True."""
-        import os
         blank = {"global_timestep": 0, "total_episodes_completed": 0, "black_wins": 0, "white_wins": 0, "draws": 0}
         if not (hasattr(file_path, "read") or os.path.exists(file_path)):
             return dict(blank, error="File not found")
