@@ -89,10 +89,21 @@ def check_head_loss_vs_oracle(ops, B, K, seed, value_clip=0, dense_rows=0, empty
     np.testing.assert_allclose(st[:6], want, rtol=5e-5, atol=5e-6)
     never = ~mask.any(axis=0)
     assert np.all(dW[never] == 0.0) and (not with_bias or np.all(dbias[never] == 0.0))   # legal nowhere: exactly zero rows
-    np.testing.assert_allclose(dfeat, odfeat, rtol=5e-5, atol=5e-6)
-    np.testing.assert_allclose(dW, odW, rtol=5e-5, atol=5e-6)
+    # Elements of a gradient row are sums that cancel: their error scales with the ROW's magnitude, not with the element.
+    # float32 logits of magnitude ~13 w_scale carry a rounding error of ~1e-6 w_scale, i.e. that relative error in every
+    # probability, which the float64 oracle (exact logits from the same float32 inputs) does not see -- a row with a
+    # near-tie and a large PPO ratio showed 7.6e-6 of its largest element at w_scale = 30 (tools/stress_head_vs_oracle.py,
+    # reproduced bit for bit by the emulator).
+    def close(got, want, what):
+        scale = np.abs(want).max(axis=-1, keepdims=True) if want.ndim > 1 else np.abs(want).max()
+        bound = 5e-5 * np.abs(want) + 5e-6 + 2e-6 * max(1.0, w_scale) * scale
+        bad = np.abs(got - want) > bound
+        assert not bad.any(), "%s: %d elements off, worst %.3g (bound %.3g)" % (
+            what, int(bad.sum()), float(np.abs(got - want)[bad].max()), float(np.broadcast_to(bound, got.shape)[bad].min()))
+    close(dfeat, odfeat, "dfeat")
+    close(dW, odW, "dW")
     if with_bias:                                                      # (no bias tensor, no bias gradient)
-        np.testing.assert_allclose(dbias, odb, rtol=5e-5, atol=5e-6)
+        close(dbias, odb, "dbias")
     np.testing.assert_allclose(dv, odv, rtol=LOSS_RTOL, atol=LOSS_ATOL)
 
 
