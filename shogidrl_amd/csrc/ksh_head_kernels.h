@@ -534,7 +534,7 @@ extern "C" __global__ void __launch_bounds__(KSH_BT_THREADS) ksh_head_bits_trans
     const int t = (int)threadIdx.x;
     if (blockIdx.y == gridDim.y - 1) {     // block-uniform
         if (blockIdx.x != 0) return;
-        if (t < 2) n_items[t] = 0u;        // work-list length, "corrupt" flag (the scan kernel is the next launch)
+        if (t < 3) n_items[t] = 0u;        // light-list length, "corrupt" flag, heavy-list length (the scan kernel is the next launch)
         ksh_ppo_stats_body(L, s_stats);
         return;
     }
@@ -580,18 +580,16 @@ extern "C" __global__ void __launch_bounds__(KSH_BT_THREADS) ksh_head_bits_trans
 
 // ------------------------------------------------------------------------------------------ weight gradient
 // dW[a][:] = sum over the samples b in which action a was legal (ascending b) of dzT[a][b] * feat[b][:], dbias[a] = the
-// sum of those dzT -- from the transposed bit matrix, without float atomics, in three small kernels so that neither the
-// ~10 000 actions that were legal nowhere nor the few that were legal almost everywhere set the pace:
-//   scan     one wave per action counts its legal samples.  Light actions (<= light_max samples: almost all of them)
-//            become ONE work item covering the whole bit row; heavy ones (a move that is legal in most positions) are
-//            split into their non-empty sample segments (at most 16).  Items are appended to a work list (one integer
-//            atomic per block picks the slots: the ORDER of the list is arbitrary, the CONTENT of every item is not);
-//            table[a] remembers where a heavy action's items start.
-//   work     a fixed-size grid of waves walks the list; an item's samples are visited in ascending order, T feature
-//            rows in flight.  A light item writes dW[a] / dbias[a] directly, a segment its partial row to scratch.
-//   combine  one wave per action: heavy actions add their partial rows in segment order (everything else returns at once:
-//            light rows were written by the work kernel, the zero rows of never-legal actions -- the zero-fill of the
-//            gradient -- by the scan kernel).
+// sum of those dzT -- from the transposed bit matrix, without float atomics, in two kernels so that neither the ~10 000
+// actions that were legal nowhere nor the few that were legal almost everywhere set the pace:
+//   scan   one wave per four actions counts their legal samples.  Light actions (<= light_max samples: almost all of
+//          them) go to the LIGHT list, heavy ones (a move that is legal in most positions) to the HEAVY list together with
+//          the mask of their non-empty sample segments (at most 16); one integer atomic per block and list picks the
+//          slots (the ORDER of a list is arbitrary, its content is not).  Actions that were legal nowhere get their zero
+//          row -- the zero-fill of the gradient -- here.
+//   work   blocks of 16 waves.  A heavy action is taken by a whole block: wave w accumulates segment w, the partial rows
+//          meet in LDS and are added in segment order.  Light actions are taken by single waves and written directly.
+//          Within a wave four 16-lane groups take every fourth sample of a 256-sample window (16 feature rows in flight).
 // Every sum has a fixed order, so the result is bit-reproducible and independent of scheduling.
 struct KshHeadDwArgs {
     const float *feat;       // [B][K]
@@ -600,24 +598,20 @@ struct KshHeadDwArgs {
     float *dW;               // [A][K]
     float *dbias;            // [A] or null
     int B, BW, K, A;
-    int SEGW, NSEG;          // dwords per segment, segments per bit row (<= 16)
-    int light_max;           // actions with at most this many legal samples are one work item
-    unsigned *n_items;       // [0] work-list length, [1] "work list corrupt" flag (both zeroed by the caller)
-    uint32_t *items;         // [A * NSEG]  action * 32 + segment (segment 31 = the whole row, result written directly)
-    int *table;              // [A][2]  first item, segment mask (0 = legal nowhere, bit 31 = light: done by the work kernel)
-    float *partial;          // [A * NSEG][K] partial rows
-    float *partial_dz;       // [A * NSEG]
+    int SEGW, NSEG;          // dwords per segment, segments per bit row (<= 16; <= 4 for K > 192)
+    int light_max;           // actions with at most this many legal samples are taken by one wave
+    unsigned *n_items;       // [0] light-list length, [1] "lists corrupt" flag, [2] heavy-list length (zeroed by the caller)
+    uint32_t *items;         // [A] light list: action ids
+    uint32_t *heavy;         // [A] heavy list: segment mask << 16 | action id
 };
 
-#define KSH_DW_WPB 4
+#define KSH_DW_WPB 16          // waves per block of the work kernel (= the most segments a heavy action can have)
 #define KSH_DW_SCAN_WPB 16
-#define KSH_DW_ALL 31u
-
 #define KSH_DW_SCAN_APW 4      // actions per wave of the scan kernel (their bit-row loads are issued together)
 
 extern "C" __global__ void __launch_bounds__(64 * KSH_DW_SCAN_WPB) ksh_head_dw_scan_kernel(KshHeadDwArgs a) {
-    __shared__ int s_cnt[KSH_DW_SCAN_WPB][KSH_DW_SCAN_APW];
-    __shared__ int s_base;
+    __shared__ int s_cl[KSH_DW_SCAN_WPB], s_ch[KSH_DW_SCAN_WPB];     // light / heavy actions of each wave
+    __shared__ int s_bl, s_bh;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int j0 = (blockIdx.x * KSH_DW_SCAN_WPB + wv) * KSH_DW_SCAN_APW;
@@ -641,23 +635,23 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_DW_SCAN_WPB) ksh_head_dw_s
             total[q] += __shfl_xor(total[q], o);
         }
     }
-    bool light[KSH_DW_SCAN_APW];
+    int nl = 0, nh = 0;
 #pragma unroll
     for (int q = 0; q < KSH_DW_SCAN_APW; q++) {
-        light[q] = total[q] > 0 && total[q] <= a.light_max;
-        if (lane == 0) s_cnt[wv][q] = total[q] == 0 ? 0 : (light[q] ? 1 : __popc(m[q]));
+        nl += (total[q] > 0 && total[q] <= a.light_max) ? 1 : 0;
+        nh += total[q] > a.light_max ? 1 : 0;
     }
+    if (lane == 0) { s_cl[wv] = nl; s_ch[wv] = nh; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 2) {                               // ONE atomic per 64 actions and list
         int sum = 0;
-        for (int w = 0; w < KSH_DW_SCAN_WPB; w++)
-            for (int q = 0; q < KSH_DW_SCAN_APW; q++) sum += s_cnt[w][q];
-        s_base = sum ? (int)atomicAdd(a.n_items, (unsigned)sum) : 0;      // ONE atomic per 64 actions
+        for (int w = 0; w < KSH_DW_SCAN_WPB; w++) sum += threadIdx.x == 0 ? s_cl[w] : s_ch[w];
+        const int base = sum ? (int)atomicAdd(a.n_items + (threadIdx.x == 0 ? 0 : 2), (unsigned)sum) : 0;
+        if (threadIdx.x == 0) s_bl = base; else s_bh = base;
     }
     __syncthreads();
-    int base = s_base;
-    for (int w = 0; w < wv; w++)
-        for (int q = 0; q < KSH_DW_SCAN_APW; q++) base += s_cnt[w][q];
+    int bl = s_bl, bh = s_bh;
+    for (int w = 0; w < wv; w++) { bl += s_cl[w]; bh += s_ch[w]; }
     const int nq = a.K >> 2;
     const bool tail = (a.K & 2) != 0;
 #pragma unroll
@@ -669,117 +663,95 @@ extern "C" __global__ void __launch_bounds__(64 * KSH_DW_SCAN_WPB) ksh_head_dw_s
             float2 *drow = reinterpret_cast<float2 *>(a.dW + (size_t)j * (size_t)a.K);
             for (int p = lane; p < 2 * nq + (tail ? 1 : 0); p += 64) drow[p] = make_float2(0.0f, 0.0f);
             if (lane == 0 && a.dbias != nullptr) a.dbias[j] = 0.0f;
-        } else if (light[q]) {
-            if (lane == 0) a.items[base] = (uint32_t)j * 32u + KSH_DW_ALL;
-        } else if (lane < 16 && ((m[q] >> lane) & 1u)) {
-            a.items[base + __popc(m[q] & ((1u << lane) - 1u))] = (uint32_t)j * 32u + (uint32_t)lane;
+        } else if (total[q] <= a.light_max) {
+            if (lane == 0) a.items[bl] = (uint32_t)j;
+            bl++;
+        } else {
+            if (lane == 0) a.heavy[bh] = (m[q] << 16) | (uint32_t)j;
+            bh++;
         }
-        if (lane == 0) { a.table[2 * j] = base; a.table[2 * j + 1] = total[q] == 0 ? 0 : (light[q] ? (int)0x80000000u : (int)m[q]); }
-        base += total[q] == 0 ? 0 : (light[q] ? 1 : __popc(m[q]));
     }
 }
 
 #define KSH_DW_WIN 256   // samples per LDS window of the work kernel
 
+// One wave accumulates dzT[j][b] * feat[b][:] over the samples b of the dwords [d0, d1) of action j's bit row, ascending,
+// and leaves the partial row at `out` (global or LDS; K floats) and the sum of the dz in *out_dz (lane 0 writes it).
 template <int KMAX>
-__global__ void __launch_bounds__(64 * KSH_DW_WPB) ksh_head_dw_work_kernel(KshHeadDwArgs a) {
+__device__ __forceinline__ void ksh_dw_accumulate(const KshHeadDwArgs &a, int j, int d0, int d1, int lane, int *rows, float *dzl,
+                                                  float *out, float *out_dz) {
     constexpr int QQ = (KMAX / 4 + 63) / 64;
     constexpr int T = 2;                    // rows in flight per group and round (4 / 8 measured slower: profiles/r02_head_kernels_pmc.txt)
     constexpr bool GROUPED = KMAX <= 192;   // 16 lanes x 3 quads cover a feature row: four samples side by side
-    const int gs = (int)(threadIdx.x & 15), gg = (int)((threadIdx.x & 63) >> 4);
-    __shared__ int s_rows[KSH_DW_WPB][KSH_DW_WIN];
-    __shared__ float s_dz[KSH_DW_WPB][KSH_DW_WIN];
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int wave = blockIdx.x * KSH_DW_WPB + wv;
-    const int nwaves = (int)gridDim.x * KSH_DW_WPB;
-    int n_items = (int)*a.n_items;
-    // A work list that cannot be right (counter beyond the list's capacity, action id beyond the table: only possible if
-    // the scratch was not cleared or was overwritten) must neither send this kernel outside its buffers nor pass silently:
-    // the list is cut / the item skipped and n_items[1] raised, which makes the combine kernel poison the gradient with NaN.
-    if (n_items < 0 || n_items > a.A * a.NSEG) {
-        if (threadIdx.x == 0) a.n_items[1] = 1u;
-        n_items = 0;
-    }
+    const int gs = lane & 15, gg = lane >> 4;
     const int nq = a.K >> 2;
     const bool tail = (a.K & 2) != 0;
-    int *rows = s_rows[wv];
-    float *dzl = s_dz[wv];
-    for (int it = wave; it < n_items; it += nwaves) {     // wave-uniform
-        const uint32_t item = a.items[it];
-        const int j = (int)(item >> 5), sg = (int)(item & 31u);
-        if (j >= a.A || (sg != (int)KSH_DW_ALL && sg >= a.NSEG)) {
-            if (lane == 0) a.n_items[1] = 1u;
-            continue;
+    const uint32_t *brow = a.bitsT + (size_t)j * (size_t)a.BW;
+    const float *zrow = a.dzT + (size_t)j * (size_t)a.B;
+    float4 acc[QQ];
+#pragma unroll
+    for (int i = 0; i < QQ; i++) acc[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 ag[3];              // GROUPED: this lane's quads gs, gs + 16, gs + 32 of its group's partial row
+#pragma unroll
+    for (int i = 0; i < 3; i++) ag[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float dzsum = 0.0f;
+    for (int c0 = d0; c0 < d1; c0 += 64) {
+        // lane = dword of the bit row; an inclusive scan of the popcounts ranks every legal sample of the chunk
+        const int d = c0 + lane;
+        const uint32_t word = d < d1 ? brow[d] : 0u;
+        const int c = __popc(word);
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl(incl, lane >= o ? lane - o : 0);
+            if (lane >= o) incl += t;
         }
-        const bool whole = sg == (int)KSH_DW_ALL;
-        const int d0 = whole ? 0 : sg * a.SEGW, d1 = whole ? a.BW : ((d0 + a.SEGW < a.BW) ? d0 + a.SEGW : a.BW);
-        const uint32_t *brow = a.bitsT + (size_t)j * (size_t)a.BW;
-        const float *zrow = a.dzT + (size_t)j * (size_t)a.B;
-        float4 acc[QQ];
-#pragma unroll
-        for (int i = 0; i < QQ; i++) acc[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        float4 ag[3];              // GROUPED: this lane's quads gs, gs + 16, gs + 32 of its group's partial row
-#pragma unroll
-        for (int i = 0; i < 3; i++) ag[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        float dzsum = 0.0f;
-        for (int c0 = d0; c0 < d1; c0 += 64) {
-            // lane = dword of the bit row; an inclusive scan of the popcounts ranks every legal sample of the chunk
-            const int d = c0 + lane;
-            const uint32_t word = d < d1 ? brow[d] : 0u;
-            const int c = __popc(word);
-            int incl = c;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int t = __shfl(incl, lane >= o ? lane - o : 0);
-                if (lane >= o) incl += t;
-            }
-            const int total = __shfl(incl, 63);
-            for (int w0 = 0; w0 < total; w0 += KSH_DW_WIN) {     // windows of 256 samples (one, as a rule), ascending
-                {
-                    int pos = incl - c;
-                    uint32_t v = word;
-                    while (v) {
-                        const int bit = __ffs((int)v) - 1;
-                        v &= v - 1u;
-                        if (pos >= w0 && pos < w0 + KSH_DW_WIN) rows[pos - w0] = 32 * d + bit;
-                        pos++;
-                    }
+        const int total = __shfl(incl, 63);
+        for (int w0 = 0; w0 < total; w0 += KSH_DW_WIN) {     // windows of 256 samples (one, as a rule), ascending
+            {
+                int pos = incl - c;
+                uint32_t v = word;
+                while (v) {
+                    const int bit = __ffs((int)v) - 1;
+                    v &= v - 1u;
+                    if (pos >= w0 && pos < w0 + KSH_DW_WIN) rows[pos - w0] = 32 * d + bit;
+                    pos++;
                 }
-                ksh_head_wave_sync();
-                const int cw = total - w0 < KSH_DW_WIN ? total - w0 : KSH_DW_WIN;
-                for (int i = lane; i < cw; i += 64) dzl[i] = zrow[rows[i]];   // all of the window's dz loads in flight at once
-                ksh_head_wave_sync();
-                if constexpr (GROUPED) {
-                    // four 16-lane groups take every fourth sample of the window: 4 T rows in flight per round, a quarter
-                    // of the rounds (an item's time is its chain of rounds: a 256-sample segment is 16 of them, not 64)
-                    for (int e0 = 0; e0 < cw; e0 += 4 * T) {
-                        float4 f[T][3];
-                        float dz[T];
-                        bool on[T];
+            }
+            ksh_head_wave_sync();
+            const int cw = total - w0 < KSH_DW_WIN ? total - w0 : KSH_DW_WIN;
+            for (int i = lane; i < cw; i += 64) dzl[i] = zrow[rows[i]];   // all of the window's dz loads in flight at once
+            ksh_head_wave_sync();
+            if constexpr (GROUPED) {
+                // four 16-lane groups take every fourth sample of the window: 4 T rows in flight per round, a quarter
+                // of the rounds (a wave's time is its chain of rounds)
+                for (int e0 = 0; e0 < cw; e0 += 4 * T) {
+                    float4 f[T][3];
+                    float dz[T];
+                    bool on[T];
 #pragma unroll
-                        for (int t = 0; t < T; t++) {
-                            const int e = e0 + 4 * t + gg;
-                            on[t] = e < cw;
-                            dz[t] = on[t] ? dzl[e] : 0.0f;
-                            const float *frow = a.feat + (size_t)rows[on[t] ? e : e0] * (size_t)a.K;
+                    for (int t = 0; t < T; t++) {
+                        const int e = e0 + 4 * t + gg;
+                        on[t] = e < cw;
+                        dz[t] = on[t] ? dzl[e] : 0.0f;
+                        const float *frow = a.feat + (size_t)rows[on[t] ? e : e0] * (size_t)a.K;
 #pragma unroll
-                            for (int i = 0; i < 3; i++) f[t][i] = ksh_ld_quad(frow, gs + 16 * i, nq, tail);
-                        }
+                        for (int i = 0; i < 3; i++) f[t][i] = ksh_ld_quad(frow, gs + 16 * i, nq, tail);
+                    }
 #pragma unroll
-                        for (int t = 0; t < T; t++) {
-                            if (on[t]) {                             // (no "+ 0 * x" terms in the sums)
-                                dzsum += dz[t];
+                    for (int t = 0; t < T; t++) {
+                        if (on[t]) {                             // (no "+ 0 * x" terms in the sums)
+                            dzsum += dz[t];
 #pragma unroll
-                                for (int i = 0; i < 3; i++) {
-                                    ag[i].x = fmaf(dz[t], f[t][i].x, ag[i].x); ag[i].y = fmaf(dz[t], f[t][i].y, ag[i].y);
-                                    ag[i].z = fmaf(dz[t], f[t][i].z, ag[i].z); ag[i].w = fmaf(dz[t], f[t][i].w, ag[i].w);
-                                }
+                            for (int i = 0; i < 3; i++) {
+                                ag[i].x = fmaf(dz[t], f[t][i].x, ag[i].x); ag[i].y = fmaf(dz[t], f[t][i].y, ag[i].y);
+                                ag[i].z = fmaf(dz[t], f[t][i].z, ag[i].z); ag[i].w = fmaf(dz[t], f[t][i].w, ag[i].w);
                             }
                         }
                     }
-                } else
-                for (int e0 = 0; e0 < cw; e0 += T) {              // feature rows: T in flight, added in ascending order
+                }
+            } else {
+                for (int e0 = 0; e0 < cw; e0 += T) {              // wide rows: lanes own quads lane + 64 i, T rows in flight
                     float4 f[T][QQ];
                     float dz[T];
 #pragma unroll
@@ -788,7 +760,7 @@ __global__ void __launch_bounds__(64 * KSH_DW_WPB) ksh_head_dw_work_kernel(KshHe
                         dz[t] = on ? dzl[e0 + t] : 0.0f;
                         const float *frow = a.feat + (size_t)(on ? rows[e0 + t] : rows[e0]) * (size_t)a.K;
 #pragma unroll
-                        for (int i = 0; i < QQ; i++) f[t][i] = ksh_ld_quad(frow, lane + 64 * i, nq, tail);   // (dz = 0 when off)
+                        for (int i = 0; i < QQ; i++) f[t][i] = ksh_ld_quad(frow, lane + 64 * i, nq, tail);
                     }
 #pragma unroll
                     for (int t = 0; t < T; t++) {
@@ -802,87 +774,101 @@ __global__ void __launch_bounds__(64 * KSH_DW_WPB) ksh_head_dw_work_kernel(KshHe
                         }
                     }
                 }
-                ksh_head_wave_sync();
             }
-        }
-        // a light action is complete: straight into the gradient; a segment of a heavy one: partial row for the combine kernel
-        float2 *prow = reinterpret_cast<float2 *>(whole ? a.dW + (size_t)j * (size_t)a.K : a.partial + (size_t)it * (size_t)a.K);
-        if constexpr (GROUPED) {
-            // the four groups' sums ((g0 + g1) + (g2 + g3): a fixed order); group i then stores quad gs + 16 i
-#pragma unroll
-            for (int o = 16; o <= 32; o <<= 1) {
-#pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    ag[i].x += __shfl_xor(ag[i].x, o); ag[i].y += __shfl_xor(ag[i].y, o);
-                    ag[i].z += __shfl_xor(ag[i].z, o); ag[i].w += __shfl_xor(ag[i].w, o);
-                }
-                dzsum += __shfl_xor(dzsum, o);
-            }
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                const int q = gs + 16 * i;
-                if (gg == i) {
-                    if (q < nq || (q == nq && tail)) prow[2 * q] = make_float2(ag[i].x, ag[i].y);
-                    if (q < nq) prow[2 * q + 1] = make_float2(ag[i].z, ag[i].w);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < QQ; i++) {
-                const int q = lane + 64 * i;
-                if (q < nq || (q == nq && tail)) prow[2 * q] = make_float2(acc[i].x, acc[i].y);
-                if (q < nq) prow[2 * q + 1] = make_float2(acc[i].z, acc[i].w);
-            }
-        }
-        if (lane == 0) {
-            if (!whole) a.partial_dz[it] = dzsum;
-            else if (a.dbias != nullptr) a.dbias[j] = dzsum;
+            ksh_head_wave_sync();
         }
     }
+    float2 *prow = reinterpret_cast<float2 *>(out);
+    if constexpr (GROUPED) {
+        // the four groups' sums ((g0 + g1) + (g2 + g3): a fixed order); group i then stores quad gs + 16 i
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                ag[i].x += __shfl_xor(ag[i].x, o); ag[i].y += __shfl_xor(ag[i].y, o);
+                ag[i].z += __shfl_xor(ag[i].z, o); ag[i].w += __shfl_xor(ag[i].w, o);
+            }
+            dzsum += __shfl_xor(dzsum, o);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int q = gs + 16 * i;
+            if (gg == i) {
+                if (q < nq || (q == nq && tail)) prow[2 * q] = make_float2(ag[i].x, ag[i].y);
+                if (q < nq) prow[2 * q + 1] = make_float2(ag[i].z, ag[i].w);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < QQ; i++) {
+            const int q = lane + 64 * i;
+            if (q < nq || (q == nq && tail)) prow[2 * q] = make_float2(acc[i].x, acc[i].y);
+            if (q < nq) prow[2 * q + 1] = make_float2(acc[i].z, acc[i].w);
+        }
+    }
+    if (lane == 0) *out_dz = dzsum;
 }
 
 template <int KMAX>
-__global__ void __launch_bounds__(64 * KSH_DW_WPB) ksh_head_dw_combine_kernel(KshHeadDwArgs a) {
-    constexpr int QQ = (KMAX / 4 + 63) / 64;
+__global__ void __launch_bounds__(64 * KSH_DW_WPB) ksh_head_dw_work_kernel(KshHeadDwArgs a) {
+    constexpr int NRED = KMAX <= 192 ? 16 : 4;            // segments of a heavy action (head_ws: maxseg)
+    __shared__ int s_rows[KSH_DW_WPB][KSH_DW_WIN];
+    __shared__ float s_dz[KSH_DW_WPB][KSH_DW_WIN];
+    __shared__ __attribute__((aligned(16))) float s_red[NRED][KMAX];
+    __shared__ float s_rdz[NRED];
     const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * KSH_DW_WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (j >= a.A) return;  // wave-uniform
-    const int nq = a.K >> 2;
-    const bool tail = (a.K & 2) != 0;
-    if (j == 0 && a.n_items[1] != 0u) {
-        // the work kernel met an impossible work list (see there): the whole gradient is unusable, say so with NaNs in the
-        // row this wave owns (every other writer of row 0 finished with the previous kernel)
-        float2 *drow = reinterpret_cast<float2 *>(a.dW);
-        for (int p = lane; p < 2 * nq + (tail ? 1 : 0); p += 64) drow[p] = make_float2(NAN, NAN);
-        if (lane == 0 && a.dbias != nullptr) a.dbias[0] = NAN;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int n_light = (int)a.n_items[0], n_heavy = (int)a.n_items[2];
+    // Lists that cannot be right (a counter beyond the number of actions: only possible if the scratch was not cleared or
+    // was overwritten) must neither send this kernel outside its buffers nor pass silently: nothing is processed and row 0
+    // of the gradient -- which no other block touches then -- is poisoned with NaN.
+    if (n_light < 0 || n_light > a.A || n_heavy < 0 || n_heavy > a.A || a.NSEG > NRED) {
+        if (blockIdx.x == 0) {
+            for (int k = (int)threadIdx.x; k < a.K; k += (int)blockDim.x) a.dW[k] = NAN;
+            if (threadIdx.x == 0) { a.n_items[1] = 1u; if (a.dbias != nullptr) a.dbias[0] = NAN; }
+        }
         return;
     }
-    const int base = a.table[2 * j];
-    const unsigned tm = (unsigned)a.table[2 * j + 1];
-    if (tm == 0u || (tm & 0x80000000u)) return;             // legal nowhere: the scan kernel wrote its zero row; light: the
-                                                            // work kernel wrote its row (wave-uniform)
-    const int cnt = __popc(tm);
-    float4 acc[QQ];
-#pragma unroll
-    for (int i = 0; i < QQ; i++) acc[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float dzsum = 0.0f;
-    for (int r = 0; r < cnt; r++) {                         // ascending segment order (the scan wrote them by rank)
-        const float *prow = a.partial + (size_t)(base + r) * (size_t)a.K;
-#pragma unroll
-        for (int i = 0; i < QQ; i++) {
-            const float4 v = ksh_ld_quad(prow, lane + 64 * i, nq, tail);
-            acc[i].x += v.x; acc[i].y += v.y; acc[i].z += v.z; acc[i].w += v.w;
+    bool bad_item = false;
+    // heavy actions: one per block, wave w = segment w, partial rows added in segment order
+    for (int h = (int)blockIdx.x; h < n_heavy; h += (int)gridDim.x) {       // block-uniform
+        const uint32_t hv = a.heavy[h];
+        const int j = (int)(hv & 0xFFFFu);
+        const uint32_t m = hv >> 16;
+        if (j >= a.A || (m >> a.NSEG) != 0u) { bad_item = true; continue; }     // (block-uniform)
+        if (wv < a.NSEG && ((m >> wv) & 1u)) {
+            const int d0 = wv * a.SEGW, d1 = (d0 + a.SEGW < a.BW) ? d0 + a.SEGW : a.BW;
+            ksh_dw_accumulate<KMAX>(a, j, d0, d1, lane, s_rows[wv], s_dz[wv], s_red[wv], &s_rdz[wv]);
         }
-        dzsum += a.partial_dz[base + r];
+        __syncthreads();
+        for (int k = (int)threadIdx.x; k < a.K; k += (int)blockDim.x) {
+            float v = 0.0f;
+            for (int sg = 0; sg < a.NSEG; sg++)
+                if ((m >> sg) & 1u) v += s_red[sg][k];
+            a.dW[(size_t)j * (size_t)a.K + (size_t)k] = v;
+        }
+        if (threadIdx.x == 0 && a.dbias != nullptr) {
+            float v = 0.0f;
+            for (int sg = 0; sg < a.NSEG; sg++)
+                if ((m >> sg) & 1u) v += s_rdz[sg];
+            a.dbias[j] = v;
+        }
+        __syncthreads();
     }
-    float2 *drow = reinterpret_cast<float2 *>(a.dW + (size_t)j * (size_t)a.K);
-#pragma unroll
-    for (int i = 0; i < QQ; i++) {
-        const int q = lane + 64 * i;
-        if (q < nq || (q == nq && tail)) drow[2 * q] = make_float2(acc[i].x, acc[i].y);
-        if (q < nq) drow[2 * q + 1] = make_float2(acc[i].z, acc[i].w);
+    // light actions: one per wave, the whole bit row, straight into the gradient
+    float dummy;
+    // (dealt out from the LAST block backwards: the heavy actions went to the first blocks)
+    for (int it = ((int)gridDim.x - 1 - (int)blockIdx.x) * KSH_DW_WPB + wv; it < n_light; it += (int)gridDim.x * KSH_DW_WPB) {     // wave-uniform
+        const int j = (int)a.items[it];
+        if (j < 0 || j >= a.A) { bad_item = true; continue; }
+        ksh_dw_accumulate<KMAX>(a, j, 0, a.BW, lane, s_rows[wv], s_dz[wv], a.dW + (size_t)j * (size_t)a.K,
+                                a.dbias != nullptr ? a.dbias + j : &dummy);
     }
-    if (lane == 0 && a.dbias != nullptr) a.dbias[j] = dzsum;
+    if (bad_item) {     // an id beyond the table (memory corruption): say so as well as a kernel without a last word can
+        if (lane == 0) a.n_items[1] = 1u;
+        for (int k = lane; k < a.K; k += 64) a.dW[k] = NAN;
+        if (lane == 0 && a.dbias != nullptr) a.dbias[0] = NAN;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ byte mask -> packed bits

@@ -397,17 +397,15 @@ static int loss_impl(const void *logits, int logits_dtype, const uint8_t *mask, 
 }
 
 // ---------------------------------------------------------------------------------- fused policy head
-// workspace layout: partial [B][8] floats | 256 B (word 0: dense-row counter, word 1: work-list length) | bitsT [A][BW] | dzT [A][B]
-//                   | items [A*NSEG] | table [A][2] | partial rows [A*NSEG][K] | partial dz [A*NSEG]
-//                   | (dense) logits scratch [B][A] | (dense) dlogits scratch [B][A]
+// workspace layout: partial [B][8] floats | 256 B (word 0: dense-row counter; words 1-3: light-list length, "lists corrupt"
+//                   flag, heavy-list length) | bitsT [A][BW] | dzT [A][B] | light list [A] | heavy list [A]
+//                   | (dense) logits scratch [B][A] | (dense) dlogits scratch [B][A] | (dense) split-K tiles
 struct HeadWs {
     float *partial;
     unsigned *n_over, *n_items;
     uint32_t *bitsT;
     float *dzT;
-    uint32_t *items;
-    int *table;
-    float *prow, *pdz;
+    uint32_t *items, *heavy;
     float *zbuf, *dlbuf, *cpart;
     int BW, SEGW, NSEG;
     size_t bytes;
@@ -423,7 +421,7 @@ static HeadWs head_ws(void *workspace, int B, int K, int dense) {
     w.n_items = w.n_over + 1;
     p += 256;
     w.BW = (B + 31) / 32;
-    const int maxseg = K <= 192 ? 16 : 4;                 // partial-row scratch is [A * NSEG][K]
+    const int maxseg = K <= 192 ? 16 : 4;                 // segments of a heavy action = waves of a work-kernel block that share it
     w.SEGW = (w.BW + maxseg - 1) / maxseg;
     w.NSEG = (w.BW + w.SEGW - 1) / w.SEGW;
     w.bitsT = (uint32_t *)p;
@@ -431,13 +429,9 @@ static HeadWs head_ws(void *workspace, int B, int K, int dense) {
     w.dzT = (float *)p;
     p += head_align((size_t)KSH_PA * B * 4);
     w.items = (uint32_t *)p;
-    p += head_align((size_t)KSH_PA * w.NSEG * 4);
-    w.table = (int *)p;
-    p += head_align((size_t)KSH_PA * 8);
-    w.prow = (float *)p;
-    p += head_align((size_t)KSH_PA * w.NSEG * K * 4);
-    w.pdz = (float *)p;
-    p += head_align((size_t)KSH_PA * w.NSEG * 4);
+    p += head_align((size_t)KSH_PA * 4);
+    w.heavy = (uint32_t *)p;
+    p += head_align((size_t)KSH_PA * 4);
     w.zbuf = w.dlbuf = w.cpart = nullptr;
     if (dense) {
         w.zbuf = (float *)p;
@@ -545,22 +539,17 @@ static int head_loss_impl(const float *feat, const float *W, const float *bias, 
         KshHeadDwArgs d;
         d.feat = feat; d.dzT = w.dzT; d.bitsT = w.bitsT; d.dW = dW; d.dbias = dbias;
         d.B = B; d.BW = w.BW; d.K = K; d.A = KSH_PA;
-        d.SEGW = w.SEGW; d.NSEG = w.NSEG; d.n_items = w.n_items; d.items = w.items; d.table = w.table;
-        d.partial = w.prow; d.partial_dz = w.pdz;
-        d.light_max = 64;
+        d.SEGW = w.SEGW; d.NSEG = w.NSEG; d.n_items = w.n_items; d.items = w.items; d.heavy = w.heavy;
+        d.light_max = 96;                                                             // (sweep: profiles/r02_head_kernels_pmc.txt)
         if (const char *lm = getenv("KSH_HEAD_LIGHT_MAX")) d.light_max = atoi(lm);     // tuning switch (tools/headdiag.py)
-        const dim3 ag((KSH_PA + KSH_DW_WPB - 1) / KSH_DW_WPB), ab(64 * KSH_DW_WPB);
         hipLaunchKernelGGL(ksh_head_dw_scan_kernel,
                            dim3((KSH_PA + KSH_DW_SCAN_WPB * KSH_DW_SCAN_APW - 1) / (KSH_DW_SCAN_WPB * KSH_DW_SCAN_APW)),
                            dim3(64 * KSH_DW_SCAN_WPB), 0, st, d);
-        // a fixed grid walks the work list (its length is only known on the device): 2048 blocks = 8192 waves
-        if (K <= 192) {
-            hipLaunchKernelGGL(ksh_head_dw_work_kernel<192>, dim3(2048), ab, 0, st, d);
-            hipLaunchKernelGGL(ksh_head_dw_combine_kernel<192>, ag, ab, 0, st, d);
-        } else {
-            hipLaunchKernelGGL(ksh_head_dw_work_kernel<1312>, dim3(2048), ab, 0, st, d);
-            hipLaunchKernelGGL(ksh_head_dw_combine_kernel<1312>, ag, ab, 0, st, d);
-        }
+        // a fixed grid walks the two lists (their lengths are only known on the device)
+        int wblocks = 768;
+        if (const char *wb = getenv("KSH_HEAD_WORK_BLOCKS")) wblocks = atoi(wb) > 0 ? atoi(wb) : wblocks;      // tuning switch
+        if (K <= 192) hipLaunchKernelGGL(ksh_head_dw_work_kernel<192>, dim3(wblocks), dim3(64 * KSH_DW_WPB), 0, st, d);
+        else hipLaunchKernelGGL(ksh_head_dw_work_kernel<1312>, dim3(wblocks), dim3(64 * KSH_DW_WPB), 0, st, d);
         if (dense) {
             // dense rows, backward: dfeat_r = dl_r W ; dW += dl^T feat and dbias += column sums over the dense rows
             g.mode = 1;

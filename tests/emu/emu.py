@@ -210,7 +210,7 @@ class EmuOps:
 
     # ---- fused policy head (ksh_head_kernels.h); masks are always handed over bit-packed
     wpa = 0          # max segments per bit row in the weight-gradient pipeline (0 = the library's choice)
-    light_max = -1   # actions with at most this many samples are one work item (-1 = the library's 64)
+    light_max = -1   # actions with at most this many samples are one work item (-1 = the library's 96)
 
     def pack_mask_kernel(self, mask):
         m8 = np.ascontiguousarray(mask, np.uint8)
