@@ -222,7 +222,10 @@ int ksh_evaluate_actions(const void *logits /*dev [B,A]*/, int logits_dtype, con
  * Semantics, RNG and stats[8] are those of ksh_masked_sample / ksh_ppo_loss_fwd_bwd with logits = feat W^T + bias;
  * outputs dfeat [B,K], dW [13527,K], dbias [13527] (or NULL), dvalues [B] are the gradients of `loss`.
  * workspace: 256-byte aligned device scratch of ksh_policy_head_workspace_bytes (loss) /
- * ksh_policy_head_evaluate_workspace_bytes (evaluate) bytes.
+ * ksh_policy_head_evaluate_workspace_bytes (evaluate) bytes (229 MB / 0.2 MB at B = 4096 without the dense path; the
+ * transposed dz matrix [13527][B] is most of it).  Diagnostic switches of the weight-gradient launch, read per call from
+ * the environment: KSH_HEAD_LIGHT_MAX (samples up to which one wave takes an action, default 96) and
+ * KSH_HEAD_WORK_BLOCKS (grid of the work kernel, default 768).
  * ---------------------------------------------------------------------------------------------- */
 int ksh_pack_mask(const uint8_t *mask /*dev [B,13527]*/, int B, uint32_t *mask_bits /*dev [B,424]*/, void *stream);
 int ksh_policy_head_sample(const float *feat, const float *W, const float *bias, int K, const uint32_t *mask_bits, int B,

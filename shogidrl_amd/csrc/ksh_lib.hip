@@ -412,7 +412,7 @@ struct HeadWs {
 };
 #define KSH_HEAD_KSPLIT 32
 static size_t head_align(size_t x) { return (x + 255) & ~(size_t)255; }
-static HeadWs head_ws(void *workspace, int B, int K, int dense) {
+static HeadWs head_ws(void *workspace, int B, int K, int dense, int grad) {      // grad = 0: the evaluate-only layout (no backward scratch)
     HeadWs w;
     char *p = (char *)workspace;
     w.partial = (float *)p;
@@ -424,22 +424,27 @@ static HeadWs head_ws(void *workspace, int B, int K, int dense) {
     const int maxseg = K <= 192 ? 16 : 4;                 // segments of a heavy action = waves of a work-kernel block that share it
     w.SEGW = (w.BW + maxseg - 1) / maxseg;
     w.NSEG = (w.BW + w.SEGW - 1) / w.SEGW;
-    w.bitsT = (uint32_t *)p;
-    p += head_align((size_t)KSH_PA * w.BW * 4);
-    w.dzT = (float *)p;
-    p += head_align((size_t)KSH_PA * B * 4);
-    w.items = (uint32_t *)p;
-    p += head_align((size_t)KSH_PA * 4);
-    w.heavy = (uint32_t *)p;
-    p += head_align((size_t)KSH_PA * 4);
+    w.bitsT = nullptr; w.dzT = nullptr; w.items = w.heavy = nullptr;
+    if (grad) {
+        w.bitsT = (uint32_t *)p;
+        p += head_align((size_t)KSH_PA * w.BW * 4);
+        w.dzT = (float *)p;
+        p += head_align((size_t)KSH_PA * B * 4);
+        w.items = (uint32_t *)p;
+        p += head_align((size_t)KSH_PA * 4);
+        w.heavy = (uint32_t *)p;
+        p += head_align((size_t)KSH_PA * 4);
+    }
     w.zbuf = w.dlbuf = w.cpart = nullptr;
     if (dense) {
         w.zbuf = (float *)p;
         p += head_align((size_t)KSH_PA * B * 4);
-        w.dlbuf = (float *)p;
-        p += head_align((size_t)KSH_PA * B * 4);
-        w.cpart = (float *)p;                              // split-K partial tiles of the dense dfeat product
-        p += head_align((size_t)KSH_HEAD_KSPLIT * B * K * 4);
+        if (grad) {
+            w.dlbuf = (float *)p;
+            p += head_align((size_t)KSH_PA * B * 4);
+            w.cpart = (float *)p;                          // split-K partial tiles of the dense dfeat product
+            p += head_align((size_t)KSH_HEAD_KSPLIT * B * K * 4);
+        }
     }
     w.bytes = (size_t)(p - (char *)workspace);
     return w;
@@ -447,7 +452,7 @@ static HeadWs head_ws(void *workspace, int B, int K, int dense) {
 
 uint64_t ksh_policy_head_workspace_bytes(int B, int K, int dense_rows_possible) {
     if (B <= 0 || K <= 0) return 0;
-    return head_ws(nullptr, B, K, dense_rows_possible).bytes;
+    return head_ws(nullptr, B, K, dense_rows_possible, 1).bytes;
 }
 
 int ksh_pack_mask(const uint8_t *mask, int B, uint32_t *mask_bits, void *stream) {
@@ -493,7 +498,7 @@ static int head_loss_impl(const float *feat, const float *W, const float *bias, 
                           const float *values, const float *old_values, int B, float clip_eps, float vf_coef, float ent_coef,
                           int value_clip, int dense, int want_grad, float *dfeat, float *dW, float *dbias, float *dvalues,
                           float *stats, float *row_logp, float *row_entropy, void *workspace, hipStream_t st) {
-    const HeadWs w = head_ws(workspace, B, K, dense);
+    const HeadWs w = head_ws(workspace, B, K, dense, want_grad);
     KshHeadArgs a;
     memset(&a, 0, sizeof a);
     a.feat = feat; a.W = W; a.bias = bias; a.K = K; a.mask_bits = mask_bits; a.B = B;
@@ -596,8 +601,8 @@ int ksh_policy_head_loss_fwd_bwd(const float *feat, const float *W, const float 
 
 uint64_t ksh_policy_head_evaluate_workspace_bytes(int B, int K, int dense_rows_possible) {
     if (B <= 0 || K <= 0) return 0;
-    // the loss workspace minus the backward scratch is not worth a second layout: same function, plus per-row dummies
-    return ksh_policy_head_workspace_bytes(B, K, dense_rows_possible) + head_align((size_t)B * 8 + 64);
+    // the forward part of the loss layout, plus per-row dummies for the loss-only inputs / outputs
+    return head_ws(nullptr, B, K, dense_rows_possible, 0).bytes + head_align((size_t)B * 8 + 64);
 }
 
 int ksh_policy_head_evaluate(const float *feat, const float *W, const float *bias, int K, const uint32_t *mask_bits,
@@ -606,7 +611,7 @@ int ksh_policy_head_evaluate(const float *feat, const float *W, const float *bia
     if (!head_common_ok("ksh_policy_head_evaluate", feat, W, K, mask_bits, B)) return KSH_E_ARG;
     if (!actions || !log_probs || !entropy || !workspace) return fail_arg("ksh_policy_head_evaluate: null pointer");
     if ((reinterpret_cast<size_t>(workspace) & 255) != 0) return fail_arg("ksh_policy_head_evaluate: workspace must be 256-byte aligned");
-    float *extra = (float *)((char *)workspace + ksh_policy_head_workspace_bytes(B, K, dense_rows_possible));
+    float *extra = (float *)((char *)workspace + head_ws(nullptr, B, K, dense_rows_possible, 0).bytes);
     float *zeros = extra, *dval = extra + B;        // loss-only inputs read zeros; dvalues / stats are discarded
     HIP_TRY(hipMemsetAsync(zeros, 0, (size_t)B * sizeof(float), (hipStream_t)stream));
     float *stats = dval + B;
