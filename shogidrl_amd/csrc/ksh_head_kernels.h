@@ -327,7 +327,9 @@ __global__ void __launch_bounds__(64 * KSH_HEAD_WPB) ksh_head_loss_kernel(KshHea
     KshFeatRegs fr;
     if constexpr (KMAX <= 192) fr = ksh_head_fetch_feat(a, b, lane);
     const int act = (int)L.actions[b];
-    const float old_lp = L.old_logp[b], Adv = L.adv[b], Vin = L.values[b], Rt = L.ret[b];
+    // (the evaluate-only call has no loss inputs: null pointers read as zeros)
+    const float old_lp = L.old_logp != nullptr ? L.old_logp[b] : 0.0f, Adv = L.adv != nullptr ? L.adv[b] : 0.0f;
+    const float Vin = L.values != nullptr ? L.values[b] : 0.0f, Rt = L.ret != nullptr ? L.ret[b] : 0.0f;
     const float ov_in = L.value_clip ? L.old_values[b] : 0.0f;
     const int n = ksh_head_collect(a.mask_bits + (size_t)b * KSH_PBITROW, lane, S.list[wv], KSH_HEAD_CAP);
     if (n > KSH_HEAD_CAP) {            // wave-uniform: a dense row, left to the MFMA path

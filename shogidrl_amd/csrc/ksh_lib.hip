@@ -613,8 +613,12 @@ int ksh_policy_head_evaluate(const float *feat, const float *W, const float *bia
     if ((reinterpret_cast<size_t>(workspace) & 255) != 0) return fail_arg("ksh_policy_head_evaluate: workspace must be 256-byte aligned");
     float *extra = (float *)((char *)workspace + head_ws(nullptr, B, K, dense_rows_possible, 0).bytes);
     float *zeros = extra, *dval = extra + B;        // loss-only inputs read zeros; dvalues / stats are discarded
-    HIP_TRY(hipMemsetAsync(zeros, 0, (size_t)B * sizeof(float), (hipStream_t)stream));
     float *stats = dval + B;
+    if (!dense_rows_possible)       // the row kernel reads null loss inputs as zeros: one launch, nothing to clear
+        return head_loss_impl(feat, W, bias, K, mask_bits, actions, nullptr, nullptr, nullptr, nullptr, nullptr, B, 0.2f, 0.0f,
+                              0.0f, 0, 0, 0, nullptr, nullptr, nullptr, dval, stats, log_probs, entropy, workspace,
+                              (hipStream_t)stream);
+    HIP_TRY(hipMemsetAsync(zeros, 0, (size_t)B * sizeof(float), (hipStream_t)stream));      // (the dense row kernel wants arrays)
     return head_loss_impl(feat, W, bias, K, mask_bits, actions, zeros, zeros, zeros, zeros, nullptr, B, 0.2f, 0.0f, 0.0f, 0,
                           dense_rows_possible, 0, nullptr, nullptr, nullptr, dval, stats, log_probs, entropy, workspace,
                           (hipStream_t)stream);
