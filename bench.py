@@ -436,7 +436,10 @@ def main():
         except Exception as e:                   # a side figure: never let it take the headline measurement down
             out["fused_policy_head"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
-            out["ppo_reference_minibatch64"] = minibatch64_rate(agent, buf, dev, note=note)
+            try:
+                out["ppo_reference_minibatch64"] = minibatch64_rate(agent, buf, dev, note=note)
+            except Exception as e:               # a side figure (needs 4096 transitions in the buffer): never the headline's problem
+                out["ppo_reference_minibatch64"] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.synchronize()
             note("minibatch-64 sample done")
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

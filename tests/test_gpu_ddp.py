@@ -153,3 +153,35 @@ def test_bench_launcher_starts_two_ranks_and_reports_them(tmp_path):
     assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["scaling"] == "weak"
     assert out["backend"].startswith("nccl" if two else "gloo")
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
+
+
+def test_bench_single_rank_line_has_the_contract_keys():
+    """`python bench.py` (one rank, no launcher) at toy sizes: ONE JSON line with every key of the driver's contract,
+    the roofline object of the env kernel and the CPU baseline object; side figures that do not fit a toy buffer report
+    an error string instead of taking the line down."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "KSH_ALLOW_GPU_SHARING", "KSH_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--games", "64", "--rollout", "4",
+                        "--epochs", "1", "--minibatch", "128", "--depth", "1", "--width", "32", "--replay", "4", "--cpu-seconds", "0.5"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and r.stdout.strip() == lines[0]
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "world_size", "backend"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 1 and out["warmup"] == 1 and out["higher_is_better"] is True
+    assert out["unit"] == "env-steps/s" and out["value"] > 0 and out["vs_baseline"] is None and out["data"] == "synthetic"
+    assert "workload" in out["config"] and "model" not in out["config"]
+    roof = out["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and "traffic" in roof
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "env-steps/s" and cb["sample"]
+    assert "error" in out["ppo_reference_minibatch64"] or out["ppo_reference_minibatch64"]["value"] > 0
