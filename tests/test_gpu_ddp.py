@@ -185,3 +185,23 @@ def test_bench_single_rank_line_has_the_contract_keys():
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "env-steps/s" and cb["sample"]
     assert "error" in out["ppo_reference_minibatch64"] or out["ppo_reference_minibatch64"]["value"] > 0
+
+
+def test_rccl_one_rank_group_accepts_every_collective_the_path_uses():
+    """RCCL needs one GPU per rank, so a one-GPU box cannot run the 2-rank test above over "nccl"; what it CAN run is a
+    one-rank RCCL communicator: library initialisation on this box plus every collective / dtype / reduce-op combination
+    of shogidrl_amd.parallel and bench.py at the bench's sizes (tests/helpers/rccl_single_rank.py)."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(here, "helpers", "rccl_single_rank.py")], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["backend"] == "nccl" and out["world_size"] == 1
+    for k in ("f32_sum_ok", "f64_sum_ok", "i64_max_ok", "f64_max_ok", "broadcast_ok"):
+        assert out[k], (k, out)
