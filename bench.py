@@ -281,7 +281,7 @@ def async_main(args, rank, world, dev, agent, env, buf, cfg, fmt, barrier, note)
     ov.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():       # (more than one rank, or a one-rank rehearsal group: KSH_DIST_REHEARSAL=1)
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.cpu()[0])
@@ -303,7 +303,7 @@ def async_main(args, rank, world, dev, agent, env, buf, cfg, fmt, barrier, note)
                        "sync_interval": args.sync_interval, "parallelism": "dp%d" % world},
             "rollout_weight_versions": ov.rollout_versions[-4:], "learner_version": ov.learner_version,
             "ppo_metrics": metrics, "episodes": ov.episode_stats()}))
-    if world > 1:
+    if dist.is_initialized():       # (more than one rank, or a one-rank rehearsal group: KSH_DIST_REHEARSAL=1)
         dist.barrier()
         dist.destroy_process_group()
 
@@ -338,7 +338,7 @@ def main():
     cfg = PPOConfig(ppo_epochs=args.epochs, minibatch_size=args.minibatch, mixed_precision=True, channels_last=True,
                     seed=42 + rank)
     agent = VecPPOAgent(model, cfg, dev)
-    if world > 1:
+    if dist.is_initialized():       # (more than one rank, or a one-rank rehearsal group: KSH_DIST_REHEARSAL=1)
         parallel.broadcast_parameters(agent.model, src=0)     # identical seeds already give identical weights; make it certain
     fmt = dict(packed_masks=True, obs_format="bf16_nhwc") if args.compact else {}
     env = VecShogiEnv(args.games, 500, device=dev, **fmt)
@@ -347,7 +347,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():       # (more than one rank, or a one-rank rehearsal group: KSH_DIST_REHEARSAL=1)
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -389,7 +389,7 @@ def main():
         note("timed step done (rollout %.2f s, update %.2f s so far)" % (roll_ms * 1e-3, upd_ms * 1e-3))
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():       # (more than one rank, or a one-rank rehearsal group: KSH_DIST_REHEARSAL=1)
         t = torch.tensor([elapsed, roll_ms, upd_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, roll_ms, upd_ms = (float(x) for x in t.cpu())
@@ -444,7 +444,7 @@ def main():
             note("minibatch-64 sample done")
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             note("cpu baseline done")
-    if world > 1:
+    if dist.is_initialized():       # (more than one rank, or a one-rank rehearsal group: KSH_DIST_REHEARSAL=1)
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

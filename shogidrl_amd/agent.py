@@ -20,7 +20,8 @@ import torch
 
 from . import ops
 from .mapper import PolicyOutputMapper
-from .parallel import FlatGradBucket, all_reduce_mean_, check_equal_batches, global_advantage_moments, sync_buffers
+from .parallel import (FlatGradBucket, all_reduce_mean_, check_equal_batches, collectives_active, global_advantage_moments,
+                       sync_buffers)
 
 
 UPDATE_GRAPH_ENV = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"     # see PPOConfig.graph_minibatch_step
@@ -276,8 +277,7 @@ class VecPPOAgent(_Acting):
         indices = np.arange(num)
         self._learn_id += 1
         graphed = bool(cfg.graph_minibatch_step and self.fused_head and num % cfg.minibatch_size == 0
-                       and not (torch.distributed.is_available() and torch.distributed.is_initialized()
-                                and torch.distributed.get_world_size(self.group) > 1))
+                       and not collectives_active(self.group))
         acc = torch.zeros(8, dtype=torch.float32, device=self.device)
         gnorm = torch.zeros((), dtype=torch.float32, device=self.device)
         updates = 0

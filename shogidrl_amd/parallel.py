@@ -17,6 +17,15 @@ import torch
 import torch.distributed as dist
 
 
+def collectives_active(group=None):
+    """True when the collectives of this module have to run: an initialised process group with more than one rank -- or
+    with ONE rank under KSH_DIST_REHEARSAL=1, which sends a single-GPU job through exactly the code and the RCCL calls
+    of a multi-GPU one (the only way to run the "nccl" path on a one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("KSH_DIST_REHEARSAL") == "1"
+
+
 def init_from_env(backend=None):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run). Returns (rank, local_rank, world)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -32,7 +41,11 @@ def init_from_env(backend=None):
                                    "(KSH_ALLOW_GPU_SHARING=1 + KSH_DIST_BACKEND=gloo rehearses on a shared GPU)"
                                    % (local_rank, ngpu))
             local_rank = local_rank % ngpu
-    if world > 1 and not dist.is_initialized():
+    rehearsal = os.environ.get("KSH_DIST_REHEARSAL") == "1"
+    if rehearsal and world == 1:      # a plain `python script.py` may rehearse too: the rendezvous of one rank with itself
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29544"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
+    if (world > 1 or rehearsal) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("KSH_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")  # "nccl" is RCCL on ROCm
         if backend == "nccl":
@@ -57,7 +70,7 @@ def check_equal_batches(num, device, group=None):
     """Raise on EVERY rank when the ranks do not hold the same number of transitions (one tiny all-reduce + host read
     per learn() call).  Without it a short rank would leave the minibatch loop early and the others would wait for
     its gradient all-reduce forever."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not collectives_active(group):
         return
     t = torch.tensor([num, -num], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
@@ -122,7 +135,7 @@ class FlatGradBucket:
             p.grad = v
 
     def all_reduce_mean(self):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if collectives_active(self.group):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.div_(dist.get_world_size(self.group))
 
@@ -131,7 +144,7 @@ def global_advantage_moments(adv, group=None):
     """(count, mean, unbiased std) of `adv` over ALL ranks from one 3-float all-reduce."""
     a = adv.reshape(-1).double()
     m = torch.stack([torch.tensor(float(a.numel()), dtype=torch.float64, device=a.device), a.sum(), (a * a).sum()])
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if collectives_active(group):
         dist.all_reduce(m, op=dist.ReduceOp.SUM, group=group)
     n, s, ss = m[0], m[1], m[2]
     mean = s / n
@@ -140,7 +153,7 @@ def global_advantage_moments(adv, group=None):
 
 
 def all_reduce_mean_(t, group=None):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if collectives_active(group):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         t.div_(dist.get_world_size(group))
     return t
@@ -149,7 +162,7 @@ def all_reduce_mean_(t, group=None):
 def broadcast_parameters(module, src=0, group=None):
     """Learner -> actors weight sync (the reference ships gzip'd state dicts through mp.Queue,
     keisei/training/parallel/communication.py:63-89); here: one RCCL broadcast per tensor."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if collectives_active(group):
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src=src, group=group)
 
@@ -159,7 +172,7 @@ def sync_buffers(module, group=None):
     every rank advances with its OWN games' batch statistics) become the mean over ranks through ONE flat all-reduce;
     integer buffers (num_batches_tracked) take the maximum.  Called at the end of every learn(), so parameters AND
     buffers -- i.e. the whole state dict -- agree across ranks whenever a checkpoint can be taken."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not collectives_active(group):
         return
     fb = [b for b in module.buffers() if b.is_floating_point()]
     ib = [b for b in module.buffers() if not b.is_floating_point()]

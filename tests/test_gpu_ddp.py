@@ -205,3 +205,24 @@ def test_rccl_one_rank_group_accepts_every_collective_the_path_uses():
     assert out["backend"] == "nccl" and out["world_size"] == 1
     for k in ("f32_sum_ok", "f64_sum_ok", "i64_max_ok", "f64_max_ok", "broadcast_ok"):
         assert out[k], (k, out)
+
+
+def test_bench_one_rank_rccl_rehearsal():
+    """KSH_DIST_REHEARSAL=1 python bench.py at toy sizes: a ONE-rank "nccl" (RCCL) process group, and with it the whole
+    multi-GPU code path -- parameter broadcast, the flat gradient all-reduce of every minibatch, the advantage moments,
+    the equal-batches check, the BatchNorm buffer sync, barriers -- runs over RCCL on the one GPU of this box."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "KSH_ALLOW_GPU_SHARING", "KSH_DIST_BACKEND", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(KSH_DIST_REHEARSAL="1", MASTER_PORT="29577")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--games", "64", "--rollout", "4",
+                        "--epochs", "2", "--minibatch", "128", "--depth", "1", "--width", "32", "--replay", "4", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["backend"] == "nccl (RCCL)" and out["world_size"] == 1 and out["n_gpus"] == 1 and out["value"] > 0
+    assert all(v == v for v in out["ppo_metrics"].values())      # finite metrics after all-reduced updates

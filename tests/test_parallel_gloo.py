@@ -170,3 +170,41 @@ def test_two_rank_batchnorm_buffers_are_synchronised_and_unequal_batches_fail_lo
     assert nb0 == nb1 == 3
     assert torch.equal(st0, st1)                            # whole state dict (parameters + buffers) identical
     assert r0 and r1                                        # the size check raised on BOTH ranks (nobody is left waiting)
+
+
+def test_one_rank_rehearsal_group_runs_the_collectives():
+    """KSH_DIST_REHEARSAL=1: a ONE-rank process group counts as distributed, so a single-GPU job goes through the same
+    collectives as a multi-GPU one (how the "nccl" path is exercised on a one-GPU box; here over gloo on the CPU)."""
+    import subprocess
+    import sys
+    code = """
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from shogidrl_amd import parallel
+assert not parallel.collectives_active()
+os.environ["KSH_DIST_REHEARSAL"] = "1"
+rank, local_rank, world = parallel.init_from_env(backend="gloo")
+assert (rank, world) == (0, 1) and dist.is_initialized() and dist.get_world_size() == 1 and parallel.collectives_active()
+lin = torch.nn.Linear(5, 3)
+b = parallel.FlatGradBucket(list(lin.parameters()))
+b.flat.copy_(torch.arange(18, dtype=torch.float32))
+b.all_reduce_mean()
+assert torch.equal(b.flat, torch.arange(18, dtype=torch.float32))
+n, mean, std = parallel.global_advantage_moments(torch.tensor([1.0, 2.0, 3.0, 6.0]))
+assert float(n) == 4 and abs(float(mean) - 3.0) < 1e-12 and abs(float(std) - torch.tensor([1.0, 2.0, 3.0, 6.0]).double().std().item()) < 1e-12
+parallel.check_equal_batches(7, "cpu")
+bn = torch.nn.BatchNorm1d(4); bn.running_mean.fill_(2.0)
+parallel.sync_buffers(bn)
+assert torch.equal(bn.running_mean, torch.full((4,), 2.0))
+parallel.broadcast_parameters(lin)
+dist.destroy_process_group()
+os.environ["KSH_DIST_REHEARSAL"] = "0"
+assert not parallel.collectives_active()
+print("REHEARSAL_OK")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "KSH_DIST_REHEARSAL"):
+        env.pop(k, None)
+    env["MASTER_PORT"] = "29561"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "REHEARSAL_OK" in r.stdout, r.stderr[-2000:]
