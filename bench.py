@@ -41,6 +41,29 @@ ENV_BYTES_PER_STEP = 28710       # obs 14 904 + mask 13 527 + st
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """From here on file descriptor 1 is stderr: whatever a library prints to stdout (RCCL writes a five-line version banner
+    there when its first communicator comes up) cannot end up next to the ONE JSON line, which emit() writes to the real
+    stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -287,7 +310,7 @@ def async_main(args, rank, world, dev, agent, env, buf, cfg, fmt, barrier, note)
         elapsed = float(t.cpu()[0])
     transitions = world * args.steps * args.rollout * args.games
     if rank == 0:
-        print(json.dumps({
+        emit({
             "metric": "env-steps/sec self-play + PPO samples/sec, 4096 games, 1/2/4/8 MI355X",
             "value": transitions / elapsed, "unit": "env-steps/s", "n_gpus": world,
             "world_size": dist.get_world_size() if dist.is_initialized() else 1,
@@ -302,7 +325,7 @@ def async_main(args, rank, world, dev, agent, env, buf, cfg, fmt, barrier, note)
                        "games_per_gpu": args.games, "rollout_len": args.rollout, "async_learner": True,
                        "sync_interval": args.sync_interval, "parallelism": "dp%d" % world},
             "rollout_weight_versions": ov.rollout_versions[-4:], "learner_version": ov.learner_version,
-            "ppo_metrics": metrics, "episodes": ov.episode_stats()}))
+            "ppo_metrics": metrics, "episodes": ov.episode_stats()})
     if dist.is_initialized():       # (more than one rank, or a one-rank rehearsal group: KSH_DIST_REHEARSAL=1)
         dist.barrier()
         dist.destroy_process_group()
@@ -316,6 +339,7 @@ def main():
         from shogidrl_amd import launch
         sys.exit(launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     from shogidrl_amd import parallel
+    quiet_stdout()
     rank, local_rank, world = parallel.init_from_env()
     if world != args.gpus:
         # the driver passes the same N to the launcher and to --gpus; anything else is a mis-launch, not a note
@@ -324,7 +348,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     if args.roofline_only:
-        print(json.dumps(env_roofline(dev, args.games, args.replay, 42)))
+        emit(env_roofline(dev, args.games, args.replay, 42))
         return
     from shogidrl_amd.agent import PPOConfig, VecPPOAgent
     from shogidrl_amd.buffer import VecExperienceBuffer
@@ -448,7 +472,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
 
 
 if __name__ == "__main__":

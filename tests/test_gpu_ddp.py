@@ -223,6 +223,8 @@ def test_bench_one_rank_rccl_rehearsal():
                         "--epochs", "2", "--minibatch", "128", "--depth", "1", "--width", "32", "--replay", "4", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout[:500]      # RCCL's version banner must not reach stdout
+    assert "RCCL version" in r.stderr
+    out = json.loads(r.stdout)
     assert out["backend"] == "nccl (RCCL)" and out["world_size"] == 1 and out["n_gpus"] == 1 and out["value"] > 0
     assert all(v == v for v in out["ppo_metrics"].values())      # finite metrics after all-reduced updates
