@@ -23,7 +23,7 @@ Both are OFF by default: an asynchronous learner changes the on-policy semantics
 import torch
 import torch.distributed as dist
 
-from . import parallel
+from . import graphs, parallel
 from .agent import ActingPolicy
 from .rollout import SelfPlayRunner
 
@@ -58,6 +58,8 @@ class OverlappedSelfPlayLearner:
 
     def __init__(self, env, agent, buffers, sync_interval=1, graphed=False, overlap=True):
         assert len(buffers) == 2
+        if graphed:
+            graphs.require_safe_replay("OverlappedSelfPlayLearner(graphed=True)")
         self.env, self.agent, self.buffers = env, agent, buffers
         self.actor = ActingPolicy(agent.model, agent.config, agent.device)
         self.runners = [SelfPlayRunner(env, self.actor, buffers[0]), SelfPlayRunner(env, self.actor, buffers[1], reset=False)]
@@ -114,7 +116,9 @@ class OverlappedSelfPlayLearner:
         # next rollout first: its launches go to the side stream and overlap the learn() enqueued right after
         self._collect_into(nxt, carry_from=cur)
         main.wait_event(self._e_roll[cur])
-        metrics = self.agent.learn(self.buffers[cur])
+        # the rollout was played by the lagging actor copy: its stored log-probs ARE the behaviour policy; they are never
+        # re-computed from the learner's newer weights (that would start the PPO ratio at 1 against the wrong policy)
+        metrics = self.agent.learn(self.buffers[cur], behaviour_is_current=False)
         self.buffers[cur]._advantages_computed = False
         self._e_learn = torch.cuda.Event()
         self._e_learn.record(main)

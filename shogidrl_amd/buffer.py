@@ -113,6 +113,10 @@ class VecExperienceBuffer:
         self.advantages = torch.zeros((T, N), dtype=torch.float32, device=d)
         self.returns = torch.zeros((T, N), dtype=torch.float32, device=d)
         self._advantages_computed = False
+        # True only while the mask rows were written by the env kernel (SelfPlayRunner sets it): such rows never hold more
+        # than 593 legal actions, which lets learn() skip the fused head's dense-row launches.  Masks from anywhere else
+        # (hand-made, e.g. the all-ones masks of the reference's unit tests) keep the dense path available.
+        self.masks_from_env = False
 
     def compute_advantages_and_returns(self, last_values):
         """last_values: float32 [N] bootstrap values of obs[T] (experience_buffer.py:99-145 per game)."""
@@ -130,7 +134,7 @@ class VecExperienceBuffer:
                "returns": f(self.returns), "dones": f(self.dones), "legal_masks": f(self.legal_masks[:T])}
         if self.legal_bits is not None:
             out["legal_bits"] = f(self.legal_bits[:T])     # what the loss kernel reads; "legal_masks" stays the contract
-        out["masks_from_env"] = True                       # written by the env kernel: never more than 593 legal actions per row
+        out["masks_from_env"] = bool(self.masks_from_env)
         return out
 
     def clear(self):

@@ -8,6 +8,8 @@ reset observation (the terminal next_obs is discarded, step_manager.py:437-468).
 obs_T bootstraps GAE and the agent learns.  Nothing in the loop synchronises with the host."""
 import torch
 
+from . import graphs
+
 
 class SelfPlayRunner:
     def __init__(self, env, agent, buffer, reset=True):
@@ -19,6 +21,7 @@ class SelfPlayRunner:
         self.global_timestep = 0
         self.episodes = torch.zeros(4, dtype=torch.int64, device=env.device)   # episodes, black wins, white wins, draws
         env.auto_reset = True
+        buffer.masks_from_env = True             # from here on every mask row of this buffer is written by the env kernel
         # both mask forms per step (contract bytes + the bit-set the kernels read) unless one of them is switched off
         self._both = env.emit_bits and not env.packed_masks
         if not reset:
@@ -43,7 +46,9 @@ class SelfPlayRunner:
         device tensor the graph increments), the env kernel writing slot t+1, the bookkeeping -- so the whole rollout
         is captured once and replayed with a single launch; trajectories are identical to collect()'s
         (tests/test_gpu_agent.py).  The first call runs one eager rollout (allocations, MIOpen solver choice), the
-        second captures, later calls replay."""
+        second captures, later calls replay.  Needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 from before the first HIP call
+        (shogidrl_amd/graphs.py), like every graph replay of this package."""
+        graphs.require_safe_replay("SelfPlayRunner.collect_graphed")
         agent = self.agent
         if getattr(self, "_graph", None) is not None:
             self._graph.replay()

@@ -4,6 +4,8 @@ Prints ONE JSON line.
 
   equal     small tower: three eager updates, one capture, replays from then on, across two learn() calls with fresh
             advantages, against the eager loop (parameters, buffers, metrics)
+  lr        the captured fused-Adam node bakes the learning rate in: after `param_groups[0]["lr"]` changes, learn() must capture a
+            new graph (and drop the old one) instead of replaying the old rate -- compared with the eager loop
   survive   bench-sized tower, minibatch 64: two learn() calls over the same rollout data, graph-replayed and eager.  The
             second learn() starts with 64 eager forward passes (the re-computed old log-probs: ~2 x 10^4 launches) -- with
             the runtime's default packet capture the replays after that returned garbage (|grad| = inf)."""
@@ -27,7 +29,7 @@ KEYS = ("ppo/policy_loss", "ppo/value_loss", "ppo/entropy", "ppo/kl_divergence_a
 mode = sys.argv[1]
 torch.backends.cudnn.deterministic = mode == "equal"      # (bit-level comparison there; "survive" compares regimes)
 out = {"mode": mode, "env": os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")}
-if mode == "equal":
+if mode in ("equal", "lr"):
     N, T = 64, 4
     res = []
     for graphed in (False, True):
@@ -36,7 +38,10 @@ if mode == "equal":
         agent = VecPPOAgent(ResTowerActorCritic(46, A, 2, 32, 0.25), cfg, DEV)
         run = SelfPlayRunner(VecShogiEnv(N, 40, device=DEV), agent, VecExperienceBuffer(T, N, cfg.gamma, cfg.lambda_gae, DEV))
         ms = []
-        for _ in range(2):
+        for it in range(2 if mode == "equal" else 3):
+            if mode == "lr" and it == 1:
+                for pg in agent.optimizer.param_groups:          # what an LR scheduler does between two learn() calls
+                    pg["lr"] = 1e-5
             run.collect()
             ms.append(run.update())
         res.append((ms, torch.cat([p.detach().reshape(-1) for p in agent.model.parameters()]).clone(),
@@ -63,7 +68,7 @@ else:
         getattr(small, name)[0].copy_(flat(getattr(buf, name)))
     small._advantages_computed = True
     for graphed in (False, True):
-        gcfg = dataclasses.replace(cfg, minibatch_size=64, graph_minibatch_step=graphed)
+        gcfg = dataclasses.replace(cfg, minibatch_size=64, graph_minibatch_step=graphed, recompute_old_log_probs=True)
         ag = VecPPOAgent(copy.deepcopy(actor.model), gcfg, DEV)
         ms = [ag.learn(small) for _ in range(2)]
         torch.cuda.synchronize()

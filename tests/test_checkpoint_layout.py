@@ -58,7 +58,6 @@ def test_update_graph_option_is_refused_without_the_runtime_setting(monkeypatch)
     constructor says so before it touches the device"""
     from shogidrl_amd.agent import PPOConfig, VecPPOAgent
     monkeypatch.delenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", raising=False)
-    monkeypatch.delenv("KSH_UNSAFE_UPDATE_GRAPH", raising=False)
     with pytest.raises(RuntimeError, match="DEBUG_CLR_GRAPH_PACKET_CAPTURE"):
         VecPPOAgent(TinyActorCritic(), PPOConfig(graph_minibatch_step=True), device="cpu")
     monkeypatch.setenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1")

@@ -461,6 +461,16 @@ def test_graph_captured_minibatch_update_equals_the_eager_loop():
     assert o["param_diff"] < 2e-5 and o["buffer_diff"] < 1e-4 and o["metric_diff"] < 1e-4, o
 
 
+def test_graph_captured_update_follows_a_changed_learning_rate():
+    """the learning rate is baked into the captured fused-Adam node.  After a scheduler-style change of
+    `param_groups[...]["lr"]` between two learn() calls the graphed learner must track the eager one (a stale graph would keep
+    stepping with 3e-4 instead of 1e-5: 30x larger steps), and hold ONE graph, not one per rate."""
+    r, o = _update_graph_check("lr")
+    assert r.returncode == 0 and o is not None, r.stderr[-2000:]
+    assert o["graphs"] == 1 and o["captured"]
+    assert o["param_diff"] < 2e-5 and o["metric_diff"] < 1e-4, o
+
+
 def test_graph_captured_update_survives_the_eager_launches_between_learn_calls():
     """bench-sized tower, minibatch 64, two learn() calls: the 64 eager forward passes that re-compute the old log-probs at
     the start of the second call are what corrupted the replays under the runtime's default packet capture (gradient norm
@@ -478,3 +488,44 @@ def test_graph_captured_update_survives_the_eager_launches_between_learn_calls()
 def test_graph_captured_update_is_refused_without_the_runtime_setting():
     r, o = _update_graph_check("equal", packet_capture_off=False)
     assert r.returncode != 0 and "DEBUG_CLR_GRAPH_PACKET_CAPTURE" in r.stderr
+
+
+def test_hand_made_dense_masks_in_a_vec_buffer_take_the_dense_path():
+    """only buffers filled by the env kernel (SelfPlayRunner sets `masks_from_env`) may promise "no dense
+    rows".  A VecExperienceBuffer filled by hand with the reference-style all-ones masks
+    (tests/core/test_ppo_agent_learning.py:53-129 use torch.ones(13527, dtype=bool)) must learn through the dense path:
+    finite loss, finite update -- and agree with the single-stream ExperienceBuffer holding the same rows."""
+    from shogidrl_amd.agent import PPOConfig, VecPPOAgent
+    from shogidrl_amd.buffer import ExperienceBuffer, VecExperienceBuffer
+    from shogidrl_amd.models import TinyActorCritic
+    N = 8
+    g = torch.Generator().manual_seed(5)
+    obs = torch.rand(N, 46, 9, 9, generator=g)
+    act = torch.randint(0, A, (N,), generator=g)
+    res = []
+    for vec in (True, False):
+        torch.manual_seed(1)
+        agent = VecPPOAgent(TinyActorCritic(), PPOConfig(ppo_epochs=2, minibatch_size=4, seed=3), DEV)
+        if vec:
+            buf = VecExperienceBuffer(1, N, 0.99, 0.95, DEV)
+            assert buf.masks_from_env is False
+            buf.obs[0].copy_(obs)
+            buf.legal_masks[0].fill_(True)
+            buf.legal_bits[0].copy_(__import__("shogidrl_amd").ops.pack_mask_bits(buf.legal_masks[0]))
+            buf.actions[0].copy_(act)
+            buf.log_probs[0].fill_(-9.5)
+            buf.values[0].fill_(0.1)
+            buf.rewards[0].copy_(torch.arange(N) % 2)
+            buf.compute_advantages_and_returns(torch.zeros(N, device=DEV))
+            assert buf.get_batch()["masks_from_env"] is False
+        else:
+            buf = ExperienceBuffer(N, 0.99, 0.95, DEV)
+            for b in range(N):
+                buf.add(obs[b], int(act[b]), float(b % 2), -9.5, 0.1, True, torch.ones(A, dtype=torch.bool))
+            buf.compute_advantages_and_returns(0.0)
+        m = agent.learn(buf)
+        assert all(np.isfinite(v) for v in m.values()), m
+        assert all(bool(torch.isfinite(p).all()) for p in agent.model.parameters())
+        res.append(m)
+    for k in res[0]:
+        assert abs(res[0][k] - res[1][k]) < 1e-5, (k, res)

@@ -99,3 +99,41 @@ def test_overlapped_rollouts_replay_on_the_oracle_across_buffer_switches():
             nobs, nmask, _, rew, done, _, _ = ora.step(buf.actions[t].cpu().numpy(), auto_reset=True)
             assert np.array_equal(buf.rewards[t].cpu().numpy(), rew) and np.array_equal(buf.dones[t].cpu().numpy().astype(np.uint8), done)
     assert ov.global_timestep == 6 * T * N                  # five learned rollouts + the one in flight
+
+
+def test_lagging_actor_keeps_its_stored_log_probs_even_when_recomputation_is_switched_on():
+    """with PPOConfig.recompute_old_log_probs=True the asynchronous learner must NOT overwrite the behaviour
+    policy's log-probs with ones computed from the learner's newer weights (the ratio would start at 1 against the wrong
+    policy and the clip would bound nothing).  A network without batch statistics makes the check exact: one epoch, one
+    minibatch = the whole rollout, so the reported KL is mean(old - new) at the learner's weights BEFORE the update --
+    zero when the data came from those very weights, non-zero when the actor copy lagged behind (sync_interval 2:
+    rollouts 0, 1, 2 are all played by version 0, the learner is at version 0, 1, 2 when it consumes them)."""
+    from shogidrl_amd.agent import PPOConfig, VecPPOAgent
+    from shogidrl_amd.async_learner import OverlappedSelfPlayLearner
+    from shogidrl_amd.buffer import VecExperienceBuffer
+    from shogidrl_amd.env import VecShogiEnv
+    from shogidrl_amd.models import TinyActorCritic
+    N, T = 64, 4
+    torch.manual_seed(3)
+    cfg = PPOConfig(ppo_epochs=1, minibatch_size=N * T, seed=5, recompute_old_log_probs=True, learning_rate=3e-3)
+    agent = VecPPOAgent(TinyActorCritic(), cfg, DEV)
+    env = VecShogiEnv(N, 40, device=DEV)
+    bufs = [VecExperienceBuffer(T, N, cfg.gamma, cfg.lambda_gae, DEV) for _ in range(2)]
+    ov = OverlappedSelfPlayLearner(env, agent, bufs, sync_interval=2)
+    kls, clips = [], []
+    for _ in range(3):
+        m = ov.step()
+        ov.synchronize()
+        kls.append(m["ppo/kl_divergence_approx"])
+        clips.append(m["ppo/clip_fraction"])
+    assert ov.rollout_versions[:3] == [0, 0, 0]
+    assert abs(kls[0]) < 1e-6 and clips[0] == 0.0              # rollout 0: played by the weights that learn from it
+    assert abs(kls[1]) > 1e-5 and abs(kls[2]) > 1e-5, kls        # rollouts 1, 2: the learner has moved on, the ratio is not 1
+    # the same stale buffer through learn() with the default behaviour_is_current=True WOULD re-compute (that is the
+    # option's meaning for a synchronous learner) and report a KL of zero: the asynchronous learner's flag is what
+    # keeps the stored values
+    stale = ov.buffers[ov._filled]
+    ov.synchronize()
+    stale._advantages_computed = True
+    m = agent.learn(stale)
+    assert abs(m["ppo/kl_divergence_approx"]) < 1e-6

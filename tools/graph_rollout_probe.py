@@ -1,18 +1,25 @@
 """Diagnostic: is a replayed ROLLOUT graph (SelfPlayRunner.collect_graphed) still bit-identical to eager rollouts after tens
 of thousands of eager kernel launches on the same stream?  (The captured PPO-update graph is not: see DESIGN.md.)
-usage: graph_rollout_probe.py depth width games [launches]"""
+usage: graph_rollout_probe.py depth width games [launches]
+Run with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (what the package requires since round 3); KSH_PROBE_DEFAULT_PACKET_CAPTURE=1 (this
+TOOL only) patches the guard to look at the runtime's default instead."""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+from shogidrl_amd import graphs
 from shogidrl_amd.agent import PPOConfig, VecPPOAgent
 from shogidrl_amd.buffer import VecExperienceBuffer
 from shogidrl_amd.env import VecShogiEnv
 from shogidrl_amd.models import ResTowerActorCritic
 from shogidrl_amd.rollout import SelfPlayRunner
 
+if os.environ.get("KSH_PROBE_DEFAULT_PACKET_CAPTURE") == "1":
+    graphs.packet_capture_off = lambda: True
+else:
+    graphs.enable_safe_replay()
 depth, width, N = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 launches = int(sys.argv[4]) if len(sys.argv) > 4 else 30000
 DEV, T = "cuda:0", 6

@@ -8,6 +8,9 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+from shogidrl_amd import graphs
+
+graphs.enable_safe_replay()                 # the rollout is replayed from a hipGraph (before the first HIP call)
 from shogidrl_amd.agent import PPOConfig, VecPPOAgent
 from shogidrl_amd.buffer import VecExperienceBuffer
 from shogidrl_amd.env import VecShogiEnv
@@ -15,7 +18,7 @@ from shogidrl_amd.models import ResTowerActorCritic
 from shogidrl_amd.rollout import SelfPlayRunner
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-# "reference": old log-probs as stored while acting (the reference's semantics); "recompute" (default for BatchNorm models):
+# "reference": old log-probs as stored while acting (the reference's semantics); "recompute" (PPOConfig.recompute_old_log_probs=True, this tool's default):
 # re-computed under learn-time statistics at the start of learn() (deviation 6)
 mode = sys.argv[2] if len(sys.argv) > 2 else "recompute"
 epochs = int(sys.argv[3]) if len(sys.argv) > 3 else 10
