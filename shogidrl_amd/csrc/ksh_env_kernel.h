@@ -193,18 +193,225 @@ struct KshBlockLds {
 // vector L1 / the L2 keep hot), a block needs 8.8 KB of LDS instead of 33.6 KB and no barrier.  Measured, not assumed:
 // DESIGN.md section 4.1.
 struct KshBlockLdsG {
+    KshLuts lut;               // the small expansion tables are staged in every variant
     KshWaveLds wave[KSH_WPB];
 };
 template <int TABG> struct KshLdsSel { typedef KshBlockLds type; };
 template <> struct KshLdsSel<1> { typedef KshBlockLdsG type; };
 __device__ __forceinline__ const KshTables &ksh_tab_of(const KshBlockLds &L, const KshTables *) { return L.tab; }
 __device__ __forceinline__ const KshTables &ksh_tab_of(const KshBlockLdsG &, const KshTables *g) { return *g; }
+__device__ __forceinline__ const KshLuts &ksh_lut_of(const KshBlockLds &L) { return L.tab.lut; }
+__device__ __forceinline__ const KshLuts &ksh_lut_of(const KshBlockLdsG &L) { return L.lut; }
 
 #define ST8(W) (reinterpret_cast<uint8_t *>((W).st32))
 
 __device__ __forceinline__ BB3 lds_bb(const uint32_t (*tbl)[81][4], int k, int sq) {
     const uint32_t *p = tbl[k][sq];
     return BB3{p[0], p[1], p[2]};
+}
+
+// Observation of the state in W.st32 (shogi/shogi_game_io.py:434-539), POV of the side to move, written with
+// coalesced 16-byte stores.  Planes 0-27 are one-hot piece planes: they are first collected as a 2 268-bit
+// set in LDS (one LDS atomic per piece) and expanded 4 bits -> 4 floats per lane; planes 28-45 are constant
+// per plane (hand counts / 18 and move_count / max_moves as the reference's double division rounded to
+// float32, the side-to-move flag, two zero planes).
+#define KSH_BOARD_F 2268  // 28 * 81
+__device__ __forceinline__ float ksh_obs_elem(const KshWaveLds &W, int f) {
+    if (f < KSH_BOARD_F) return ((W.obsbits[f >> 5] >> (f & 31)) & 1u) ? 1.0f : 0.0f;
+    return W.metav[(unsigned)(f - KSH_BOARD_F) / 81u];
+}
+// planes 28-45 as float32 values into W.metav (callers sync afterwards)
+__device__ __forceinline__ void ksh_obs_meta(KshWaveLds &W, const KshLuts &LU, const KshStepArgs &a, int lane, int mf_idx,
+                                             float mf_hint) {
+    const uint8_t *st8 = ST8(W);
+    const int side = st8[S_SIDE];
+    // move_count / max_moves in double, stored as float32 (:535-536).  The state record carries the value for its NEXT
+    // move count (computed by the previous step after its stores were out); anything else -- a freshly reset or loaded
+    // position -- is divided here, behind a wave-uniform branch so that the common path never issues the f64 division.
+    const int mcount = __builtin_amdgcn_readfirstlane((int)(st8[S_MC] | (st8[S_MC + 1] << 8)));
+    float mfv = mf_hint;
+    if (mcount != __builtin_amdgcn_readfirstlane(mf_idx))
+        mfv = a.max_moves > 0 ? (float)((double)mcount / (double)a.max_moves) : 0.0f;
+    if (lane < 14) {
+        // planes 28-34 own hand, 35-41 opponent hand; count/18.0 in double, stored as float32 (:513-527): host-built table
+        const int cidx = lane < 7 ? side : 1 - side;
+        const int cnt = st8[S_HAND + 7 * cidx + (lane < 7 ? lane : lane - 7)];
+        W.metav[lane] = cnt < 20 ? LU.hand18[cnt] : (float)((double)cnt / 18.0);
+    } else if (lane == 14) {
+        W.metav[14] = side == 0 ? 1.0f : 0.0f;
+    } else if (lane == 15) {
+        W.metav[15] = mfv;
+    } else if (lane < 20) {
+        W.metav[lane] = 0.0f;
+    }
+}
+// The float32 observation writer in parts: ksh_obs_begin builds the bit-set of planes 0-27 and the 18 plane constants in
+// LDS, writes the few floats outside the aligned chunks and returns the lane's plan; ksh_obs_board / ksh_obs_metar issue
+// rounds [IT0, IT0 + N) of it.  (Round 3 measured issuing the 15 rounds in pieces BETWEEN the phases of the move generator,
+// to overlap the store path with the generator's latency chain: 24.6-24.9 us against 24.1-24.2 us for all rounds at once at
+// 4096 games -- profiles/r03_env_variants.log -- so ksh_write_obs issues them in one go.)
+struct KshObsPlan {
+    float *o0;            // planes 0-27: address of this lane's chunk in round 0 (round it: + 256 floats)
+    const uint32_t *bw;   //   bit-set word holding that chunk's first bit (round it: + 8 words)
+    float *om;            // planes 28-45: address of this lane's chunk in round 0
+    int sh;               //   shift of the chunk's first bit inside bw[0] (the same in every round)
+    int nb;               // rounds' bounds: a board chunk exists while lane + 64 it < nb, a meta chunk while lane + 64 it < nm
+    int nm;
+    int rem, p0;          // meta: offset of the chunk's first float inside its plane, metav index of that plane (advance per round)
+};
+__device__ __forceinline__ KshObsPlan ksh_obs_begin(KshWaveLds &W, const KshLuts &LU, const KshStepArgs &a, int g, int lane, int mf_idx,
+                                                    float mf_hint) {
+    const uint8_t *st8 = ST8(W);
+    const int side = st8[S_SIDE];
+    for (int i = lane; i < 80; i += 64) W.obsbits[i] = 0;
+    wave_lds_sync();
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const int s = pass * 64 + lane;
+        if (s < 81 && st8[s] != 0) {
+            const int pc = st8[s];
+            const int col = pc >= 15 ? 1 : 0;
+            const int t = pc - 1 - 14 * col;
+            const int bit = ((col == side ? 0 : 14) + t) * 81 + (side == 0 ? s : 80 - s);   // both r and c mirrored (:468-469)
+            atomicOr(&W.obsbits[bit >> 5], 1u << (bit & 31));
+        }
+    }
+    ksh_obs_meta(W, LU, a, lane, mf_idx, mf_hint);
+    wave_lds_sync();
+    // Row g starts at a 4-byte aligned address (rows are 14 904 B apart, so even when the tensor itself is 16-byte
+    // aligned every other row is not): `head` floats are written singly up to the first 16-byte boundary, then
+    // aligned 16-byte chunks, then the 0-3 remaining floats.
+    float *orow = a.obs + (size_t)g * KSH_OBSF;
+    const int head = (int)(((16 - (reinterpret_cast<size_t>(orow) & 15)) & 15) >> 2);
+    const int nfull = (KSH_OBSF - head) >> 2;       // 930 or 931 aligned chunks
+    const int nboard = (KSH_BOARD_F - head) >> 2;   // chunks lying entirely inside planes 0-27
+    KshObsPlan pl;
+    // planes 0-27: round `it` of lane l is the chunk 256 floats after round it-1's, so the bit-set word index advances by 8
+    // and the shift never changes; the four floats come out of the 16-entry nibble table (one 16-byte LDS read)
+    const int f0 = head + 4 * lane;
+    pl.sh = f0 & 31;
+    pl.bw = &W.obsbits[f0 >> 5];
+    pl.o0 = orow + f0;
+    pl.nb = nboard;
+    // planes 28-45 are constant per plane; a chunk touches at most two of them.  Plane and offset of a lane's chunk are
+    // divided out once and advanced by 256 = 3 * 81 + 13 floats per round.  (One plane of bias keeps the division unsigned
+    // for the chunk that straddles plane 27 / 28; that chunk is written on its own right here.)
+    const int fm = head + 4 * (nboard + lane);
+    const int mm = fm - KSH_BOARD_F + 81;
+    const int pp = (int)((unsigned)mm / 81u);
+    pl.rem = mm - 81 * pp;
+    pl.p0 = pp - 1;                                 // -1: the straddling chunk (lane 0, round 0)
+    pl.om = orow + fm;
+    pl.nm = nfull - nboard;
+    if (((KSH_BOARD_F - head) & 3) != 0 && lane == 0) {   // wave-uniform outer condition: every other row has such a chunk
+        const int f = head + 4 * nboard;
+        ksh_store16(orow + f, uint4{__float_as_uint(ksh_obs_elem(W, f)), __float_as_uint(ksh_obs_elem(W, f + 1)),
+                                    __float_as_uint(ksh_obs_elem(W, f + 2)), __float_as_uint(ksh_obs_elem(W, f + 3))});
+    }
+    if (lane < head) orow[lane] = ((W.obsbits[0] >> lane) & 1u) ? 1.0f : 0.0f;     // head <= 3: plane 0
+    const int tail0 = head + 4 * nfull;
+    if (lane < KSH_OBSF - tail0) orow[tail0 + lane] = W.metav[17];                  // the last floats of plane 45
+    return pl;
+}
+template <int IT0, int N>
+__device__ __forceinline__ void ksh_obs_board(const KshLuts &LU, const KshObsPlan &pl, int lane) {
+    const uint4 *nib = reinterpret_cast<const uint4 *>(LU.nib_f32);
+#pragma unroll
+    for (int it = IT0; it < IT0 + N; it++) {        // 9 rounds in all: 9 * 64 >= 567
+        if (lane + 64 * it < pl.nb) {
+            const uint32_t x = __funnelshift_r(pl.bw[8 * it], pl.bw[8 * it + 1], pl.sh);
+            ksh_store16(pl.o0 + 256 * it, nib[x & 15u]);
+        }
+    }
+}
+template <int IT0, int N>
+__device__ __forceinline__ void ksh_obs_metar(const KshWaveLds &W, KshObsPlan &pl, int lane) {
+#pragma unroll
+    for (int it = IT0; it < IT0 + N; it++) {        // 6 rounds in all: 6 * 64 >= 931 - 566
+        if (lane + 64 * it < pl.nm && (it > 0 || pl.p0 >= 0)) {
+            const float v0 = W.metav[pl.p0], v1 = W.metav[pl.p0 + 1];      // p0 + 1 <= 18 < 20: in bounds
+            const int r = 81 - pl.rem;              // floats of plane p0 from the chunk's first one on
+            const float4 v = make_float4(v0, 1 < r ? v0 : v1, 2 < r ? v0 : v1, 3 < r ? v0 : v1);
+            ksh_store16(pl.om + 256 * it, uint4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)});
+        }
+        pl.rem += 13;
+        pl.p0 += 3;
+        if (pl.rem >= 81) { pl.rem -= 81; pl.p0 += 1; }
+    }
+}
+// the whole observation at once (reset / observe paths, and the rewrite after an auto-reset)
+__device__ __forceinline__ void ksh_write_obs(KshWaveLds &W, const KshLuts &LU, const KshStepArgs &a, int g, int lane, int mf_idx,
+                                              float mf_hint) {
+    KshObsPlan pl = ksh_obs_begin(W, LU, a, g, lane, mf_idx, mf_hint);
+    ksh_obs_board<0, 9>(LU, pl, lane);
+    ksh_obs_metar<0, 6>(W, pl, lane);
+}
+
+// Compact observation (SURVEY 8 f4; not part of the reference contract): the same 46 planes as bfloat16 in
+// channels-last order -- element (pov_sq, ch) at row[pov_sq * 46 + ch], 7 452 B per game instead of 14 904 --
+// which is bit for bit what `obs.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)` holds (round to
+// nearest even of the float32 plane values), i.e. exactly the tensor the bf16-autocast stem convolution consumes.
+// A dword holds channels (2k, 2k+1) of one square (46 is even): for k < 14 it is a one-hot test against the
+// square's plane index, for k >= 14 one of nine precomputed pairs of the constant planes.
+#define KSH_OBS16_DW 1863  // 81 * 46 / 2
+__device__ __forceinline__ uint32_t ksh_obs_bf16(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return (b + 0x7FFFu + ((b >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ uint32_t ksh_obs16_dword(const uint8_t *plane, const uint32_t *pair, int d) {
+    const int sq = (int)((unsigned)d / 23u);
+    const int k = d - 23 * sq;
+    const uint32_t pl = plane[sq];
+    if (k >= 14) return pair[k - 14];
+    return (int)(pl >> 1) == k ? (0x3F80u << ((pl & 1u) * 16u)) : 0u;
+}
+__device__ __forceinline__ void ksh_write_obs16(KshWaveLds &W, const KshLuts &LU, const KshStepArgs &a, int g, int lane, int mf_idx,
+                                                float mf_hint) {
+    const uint8_t *st8 = ST8(W);
+    const int side = st8[S_SIDE];
+    uint8_t *plane = reinterpret_cast<uint8_t *>(W.obsbits);       // [81] plane index of the piece on each POV square, 0xFF = empty
+    uint32_t *pair = W.obsbits + 24;                                // [9] bf16 pairs of planes 28-45
+    if (lane < 24) W.obsbits[lane] = 0xFFFFFFFFu;
+    wave_lds_sync();
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const int s = pass * 64 + lane;
+        if (s < 81 && st8[s] != 0) {
+            const int pc = st8[s];
+            const int col = pc >= 15 ? 1 : 0;
+            const int t = pc - 1 - 14 * col;
+            plane[side == 0 ? s : 80 - s] = (uint8_t)((col == side ? 0 : 14) + t);
+        }
+    }
+    ksh_obs_meta(W, LU, a, lane, mf_idx, mf_hint);
+    wave_lds_sync();
+    if (lane < 9) pair[lane] = ksh_obs_bf16(W.metav[2 * lane]) | (ksh_obs_bf16(W.metav[2 * lane + 1]) << 16);
+    wave_lds_sync();
+    uint32_t *orow = reinterpret_cast<uint32_t *>(a.obs) + (size_t)g * KSH_OBS16_DW;   // rows are 4-byte aligned (7 452 B apart)
+    const int head = (int)(((16 - (reinterpret_cast<size_t>(orow) & 15)) & 15) >> 2);
+    const int nfull = (KSH_OBS16_DW - head) >> 2;   // 465 aligned 16-byte chunks
+#pragma unroll
+    for (int it = 0; it < 8; it++) {                // 8 * 64 >= 465
+        const int c = lane + 64 * it;
+        if (c < nfull) {
+            const int d = head + 4 * c;
+            int sq = (int)((unsigned)d / 23u);
+            int k = d - 23 * sq;
+            uint32_t pl = plane[sq];
+            const uint32_t pl_next = plane[sq + 1];  // sq + 1 <= 81: still inside obsbits
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                w[j] = k >= 14 ? pair[k - 14] : ((int)(pl >> 1) == k ? (0x3F80u << ((pl & 1u) * 16u)) : 0u);
+                k++;
+                if (k == 23) { k = 0; pl = pl_next; }
+            }
+            ksh_store16(orow + d, uint4{w[0], w[1], w[2], w[3]});
+        }
+    }
+    if (lane < head) orow[lane] = ksh_obs16_dword(plane, pair, lane);
+    const int tail0 = head + 4 * nfull;
+    if (lane < KSH_OBS16_DW - tail0) orow[tail0 + lane] = ksh_obs16_dword(plane, pair, tail0 + lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -219,38 +426,43 @@ __device__ __forceinline__ BB3 lds_bb(const uint32_t (*tbl)[81][4], int k, int s
 
 // ---- emission helpers: the action ids of one from-square are the 160 consecutive bits [160*from, 160*from+160)
 // of the legal bit-set (utils/utils.py:208-241: id = ((from*80 + to - (to > from))*2 + promote), i.e. exactly five
-// dwords that no other piece writes.  They are built without loops: the 81-bit target sets (non-promoting /
-// promoting) are made contiguous, the from-square is squeezed out window by window, and the two sets are
-// bit-interleaved.
+// dwords that no other piece writes.  They are built without loops: the two 81-bit target sets (non-promoting /
+// promoting) are made contiguous, the from-square is squeezed out of each stream once (three funnel shifts and three
+// bit-field inserts), and the two 80-bit streams are bit-interleaved 16 + 16 bits at a time through the byte-spread
+// table in LDS (round 3: the arithmetic interleave was 324 of the kernel's 1 795 VALU instructions per game-step).
 struct Stream81 {
     uint32_t c0, c1, c2;
 };
 __device__ __forceinline__ Stream81 bb_stream(BB3 b) {
     return Stream81{b.w0 | (b.w1 << 27), (b.w1 >> 5) | (b.w2 << 22), b.w2 >> 10};
 }
-// 16 bits starting at (compile-time) bit p of the stream
-template <int P>
-__device__ __forceinline__ uint32_t stream_ext16(Stream81 x) {
-    constexpr int w = P >> 5, sh = P & 31;
-    const uint32_t lo = w == 0 ? x.c0 : (w == 1 ? x.c1 : (w == 2 ? x.c2 : 0u));
-    const uint32_t hi = w == 0 ? x.c1 : (w == 1 ? x.c2 : 0u);
-    return __funnelshift_r(lo, hi, sh) & 0xFFFFu;
+// (a & m) | (b & ~m): one v_bfi_b32
+__device__ __forceinline__ uint32_t ksh_bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+// the three words of the 81-bit mask "bits below `from`"
+struct Low81 {
+    uint32_t m0, m1, m2;
+};
+__device__ __forceinline__ Low81 low_mask81(int from) {
+    Low81 m;
+    m.m0 = from >= 32 ? 0xFFFFFFFFu : ((1u << (from & 31)) - 1u);
+    m.m1 = from <= 32 ? 0u : (from >= 64 ? 0xFFFFFFFFu : ((1u << ((from - 32) & 31)) - 1u));
+    m.m2 = from <= 64 ? 0u : ((1u << ((from - 64) & 31)) - 1u);
+    return m;
 }
-__device__ __forceinline__ uint32_t spread16(uint32_t x) {  // bit i -> bit 2i
-    x = (x | (x << 8)) & 0x00FF00FFu;
-    x = (x | (x << 4)) & 0x0F0F0F0Fu;
-    x = (x | (x << 2)) & 0x33333333u;
-    x = (x | (x << 1)) & 0x55555555u;
-    return x;
+// drop bit `from` out of the stream: the bits above it move down by one (80 bits remain)
+__device__ __forceinline__ Stream81 stream_squeeze(Stream81 x, Low81 m) {
+    const uint32_t t0 = __funnelshift_r(x.c0, x.c1, 1), t1 = __funnelshift_r(x.c1, x.c2, 1), t2 = x.c2 >> 1;
+    return Stream81{ksh_bfi(m.m0, x.c0, t0), ksh_bfi(m.m1, x.c1, t1), ksh_bfi(m.m2, x.c2, t2)};
 }
-// dword K (0..4) of the from-square's slice: targets j' in [16K, 16K+16) of the 80-entry "to without from" order
+// dword K (0..4) of the slice: bits [16K, 16K+16) of the two squeezed streams, interleaved (non-promoting even, promoting odd)
 template <int K>
-__device__ __forceinline__ uint32_t slice_word(Stream81 tn, Stream81 tp, int from) {
-    const int r = from - 16 * K;                                  // how many of this window's entries lie below `from`
-    const uint32_t m = r <= 0 ? 0u : (r >= 16 ? 0xFFFFu : ((1u << r) - 1u));
-    const uint32_t n = (stream_ext16<16 * K>(tn) & m) | (stream_ext16<16 * K + 1>(tn) & ~m & 0xFFFFu);
-    const uint32_t q = (stream_ext16<16 * K>(tp) & m) | (stream_ext16<16 * K + 1>(tp) & ~m & 0xFFFFu);
-    return spread16(n) | (spread16(q) << 1);
+__device__ __forceinline__ uint32_t slice_word(const KshLuts &LU, Stream81 n, Stream81 q) {
+    const uint32_t nw = (K >> 1) == 0 ? n.c0 : ((K >> 1) == 1 ? n.c1 : n.c2);
+    const uint32_t qw = (K >> 1) == 0 ? q.c0 : ((K >> 1) == 1 ? q.c1 : q.c2);
+    constexpr int sh = (K & 1) * 16;
+    const uint32_t n0 = LU.spread8[(nw >> sh) & 0xFFu], n1 = LU.spread8[(nw >> (sh + 8)) & 0xFFu];
+    const uint32_t q0 = LU.spread8[(qw >> sh) & 0xFFu], q1 = LU.spread8[(qw >> (sh + 8)) & 0xFFu];
+    return (n0 | (n1 << 16)) | ((q0 | (q1 << 16)) << 1);
 }
 
 #ifdef KSH_STAMPS
@@ -263,8 +475,8 @@ __device__ __forceinline__ uint32_t slice_word(Stream81 tn, Stream81 tp, int fro
 #else
 #define GEN_STAMP(k) do { } while (0)
 #endif
-__device__ __forceinline__ int ksh_gen(const KshTables &TB, KshWaveLds &W, int lane, int me, bool emit, bool want_ufz,
-                                       bool &in_check, BB3 &ufz_cand, unsigned long long *dbg = nullptr) {
+__device__ __forceinline__ int ksh_gen(const KshTables &TB, const KshLuts &LU, KshWaveLds &W, int lane, int me, bool emit,
+                                       bool want_ufz, bool &in_check, BB3 &ufz_cand, unsigned long long *dbg = nullptr) {
     const uint8_t *brd = ST8(W);
     const int p0 = brd[lane];
     const int p1 = (lane < 17) ? brd[64 + lane] : 0;
@@ -404,13 +616,14 @@ __device__ __forceinline__ int ksh_gen(const KshTables &TB, KshWaveLds &W, int l
         const BB3 Tn = bb_andn(T, must);
         cnt = __popc(Tp.w0) + __popc(Tp.w1) + __popc(Tp.w2) + __popc(Tn.w0) + __popc(Tn.w1) + __popc(Tn.w2);
         if (emit && cnt != 0) {
-            const Stream81 sn = bb_stream(Tn), sp = bb_stream(Tp);
+            const Low81 lm = low_mask81(sq);
+            const Stream81 sn = stream_squeeze(bb_stream(Tn), lm), sp = stream_squeeze(bb_stream(Tp), lm);
             uint32_t *out = &W.maskbits[5 * sq];             // this from-square's private 160-bit slice
-            out[0] = slice_word<0>(sn, sp, sq);
-            out[1] = slice_word<1>(sn, sp, sq);
-            out[2] = slice_word<2>(sn, sp, sq);
-            out[3] = slice_word<3>(sn, sp, sq);
-            out[4] = slice_word<4>(sn, sp, sq);
+            out[0] = slice_word<0>(LU, sn, sp);
+            out[1] = slice_word<1>(LU, sn, sp);
+            out[2] = slice_word<2>(LU, sn, sp);
+            out[3] = slice_word<3>(LU, sn, sp);
+            out[4] = slice_word<4>(LU, sn, sp);
         }
     }
 
@@ -462,11 +675,11 @@ __device__ __forceinline__ int ksh_gen(const KshTables &TB, KshWaveLds &W, int l
 // Legal moves of `me` including the uchi-fu-zume decision (shogi_rules_logic.py:275-359): for every
 // candidate square drop the pawn on the LDS board, generate the opponent's replies (nested pawn drops
 // skip their own test, :461-467) and keep the drop unless it gives check AND leaves no reply.
-__device__ __forceinline__ int ksh_gen_full(const KshTables &TB, KshWaveLds &W, int lane, int me, bool &in_check,
-                                            unsigned long long *dbg = nullptr) {
+__device__ __forceinline__ int ksh_gen_full(const KshTables &TB, const KshLuts &LU, KshWaveLds &W, int lane, int me,
+                                            bool &in_check, unsigned long long *dbg = nullptr) {
     uint8_t *st8 = ST8(W);
     BB3 cand;
-    int n = ksh_gen(TB, W, lane, me, true, true, in_check, cand, dbg);
+    int n = ksh_gen(TB, LU, W, lane, me, true, true, in_check, cand, dbg);
 #ifdef KSH_STAMPS
     if (lane == 0 && dbg) { dbg[10] = __builtin_amdgcn_s_memtime(); dbg[9] = bb_any(cand) ? 1 : 0; }
 #endif
@@ -477,7 +690,7 @@ __device__ __forceinline__ int ksh_gen_full(const KshTables &TB, KshWaveLds &W, 
         wave_lds_sync();
         bool gives_check;
         BB3 none;
-        const int replies = ksh_gen(TB, W, lane, 1 - me, false, false, gives_check, none);
+        const int replies = ksh_gen(TB, LU, W, lane, 1 - me, false, false, gives_check, none);
         if (lane == 0) st8[s] = 0;
         wave_lds_sync();
         if (!(gives_check && replies == 0)) {
@@ -490,172 +703,17 @@ __device__ __forceinline__ int ksh_gen_full(const KshTables &TB, KshWaveLds &W, 
     return n;
 }
 
-// Observation of the state in W.st32 (shogi/shogi_game_io.py:434-539), POV of the side to move, written with
-// coalesced 16-byte stores.  Planes 0-27 are one-hot piece planes: they are first collected as a 2 268-bit
-// set in LDS (one LDS atomic per piece) and expanded 4 bits -> 4 floats per lane; planes 28-45 are constant
-// per plane (hand counts / 18 and move_count / max_moves as the reference's double division rounded to
-// float32, the side-to-move flag, two zero planes).
-#define KSH_BOARD_F 2268  // 28 * 81
-__device__ __forceinline__ float ksh_obs_elem(const KshWaveLds &W, int f) {
-    if (f < KSH_BOARD_F) return ((W.obsbits[f >> 5] >> (f & 31)) & 1u) ? 1.0f : 0.0f;
-    return W.metav[(unsigned)(f - KSH_BOARD_F) / 81u];
-}
-// planes 28-45 as float32 values into W.metav (callers sync afterwards)
-__device__ __forceinline__ void ksh_obs_meta(KshWaveLds &W, const KshStepArgs &a, int lane, int mf_idx, float mf_hint) {
-    const uint8_t *st8 = ST8(W);
-    const int side = st8[S_SIDE];
-    if (lane < 14) {
-        // planes 28-34 own hand, 35-41 opponent hand; count/18.0 in double, stored as float32 (:513-527)
-        const int cidx = lane < 7 ? side : 1 - side;
-        const int cnt = st8[S_HAND + 7 * cidx + (lane < 7 ? lane : lane - 7)];
-        W.metav[lane] = (float)((double)cnt / 18.0);
-    } else if (lane == 14) {
-        W.metav[14] = side == 0 ? 1.0f : 0.0f;
-    } else if (lane == 15) {
-        // move_count / max_moves in double, stored as float32 (:535-536): host-built table, division only past its end
-        const int mcount = st8[S_MC] | (st8[S_MC + 1] << 8);
-        // the state record carries the value for its NEXT move count; anything else is divided here
-        W.metav[15] = mcount == mf_idx ? mf_hint
-                                       : (a.max_moves > 0 ? (float)((double)mcount / (double)a.max_moves) : 0.0f);
-    } else if (lane < 20) {
-        W.metav[lane] = 0.0f;
-    }
-}
-__device__ __forceinline__ void ksh_write_obs(KshWaveLds &W, const KshStepArgs &a, int g, int lane, int mf_idx, float mf_hint) {
-    const uint8_t *st8 = ST8(W);
-    const int side = st8[S_SIDE];
-    for (int i = lane; i < 80; i += 64) W.obsbits[i] = 0;
-    wave_lds_sync();
-#pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-        const int s = pass * 64 + lane;
-        if (s < 81 && st8[s] != 0) {
-            const int pc = st8[s];
-            const int col = pc >= 15 ? 1 : 0;
-            const int t = pc - 1 - 14 * col;
-            const int bit = ((col == side ? 0 : 14) + t) * 81 + (side == 0 ? s : 80 - s);   // both r and c mirrored (:468-469)
-            atomicOr(&W.obsbits[bit >> 5], 1u << (bit & 31));
-        }
-    }
-    ksh_obs_meta(W, a, lane, mf_idx, mf_hint);
-    wave_lds_sync();
-    // Row g starts at a 4-byte aligned address (rows are 14 904 B apart, so even when the tensor itself is 16-byte
-    // aligned every other row is not): `head` floats are written singly up to the first 16-byte boundary, then
-    // aligned 16-byte chunks, then the 0-3 remaining floats.
-    float *orow = a.obs + (size_t)g * KSH_OBSF;
-    const int head = (int)(((16 - (reinterpret_cast<size_t>(orow) & 15)) & 15) >> 2);
-    const int nfull = (KSH_OBSF - head) >> 2;       // 930 or 931 aligned chunks
-    const int nboard = (KSH_BOARD_F - head) >> 2;   // chunks lying entirely inside planes 0-27
-#pragma unroll
-    for (int it = 0; it < 9; it++) {                // 9 * 64 >= 567: constant trip count so the LDS reads batch up
-        const int c = lane + 64 * it;
-        if (c < nboard) {
-            const int f = head + 4 * c;
-            const uint32_t x = __funnelshift_r(W.obsbits[f >> 5], W.obsbits[(f >> 5) + 1], f & 31);
-            uint4 v;
-            v.x = (x & 1u) ? 0x3F800000u : 0u;
-            v.y = (x & 2u) ? 0x3F800000u : 0u;
-            v.z = (x & 4u) ? 0x3F800000u : 0u;
-            v.w = (x & 8u) ? 0x3F800000u : 0u;
-            ksh_store16(orow + f, v);
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < 6; it++) {                // 6 * 64 >= 931 - 566
-        const int c = nboard + lane + 64 * it;
-        if (c < nfull) {
-            const int f = head + 4 * c;
-            float4 v;
-            if (f >= KSH_BOARD_F) {                 // at most two planes per chunk: two LDS reads + selects
-                const int p0 = (int)((unsigned)(f - KSH_BOARD_F) / 81u);
-                const int next = KSH_BOARD_F + 81 * (p0 + 1);
-                const float v0 = W.metav[p0], v1 = W.metav[p0 + 1 < 18 ? p0 + 1 : 17];
-                v = make_float4(v0, f + 1 < next ? v0 : v1, f + 2 < next ? v0 : v1, f + 3 < next ? v0 : v1);
-            } else {                                // the one chunk straddling plane 27 / 28
-                v = make_float4(ksh_obs_elem(W, f), ksh_obs_elem(W, f + 1), ksh_obs_elem(W, f + 2), ksh_obs_elem(W, f + 3));
-            }
-            ksh_store16(orow + f, uint4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)});
-        }
-    }
-    if (lane < head) orow[lane] = ksh_obs_elem(W, lane);
-    const int tail0 = head + 4 * nfull;
-    if (lane < KSH_OBSF - tail0) orow[tail0 + lane] = ksh_obs_elem(W, tail0 + lane);
-}
-
-// Compact observation (SURVEY 8 f4; not part of the reference contract): the same 46 planes as bfloat16 in
-// channels-last order -- element (pov_sq, ch) at row[pov_sq * 46 + ch], 7 452 B per game instead of 14 904 --
-// which is bit for bit what `obs.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)` holds (round to
-// nearest even of the float32 plane values), i.e. exactly the tensor the bf16-autocast stem convolution consumes.
-// A dword holds channels (2k, 2k+1) of one square (46 is even): for k < 14 it is a one-hot test against the
-// square's plane index, for k >= 14 one of nine precomputed pairs of the constant planes.
-#define KSH_OBS16_DW 1863  // 81 * 46 / 2
-__device__ __forceinline__ uint32_t ksh_obs_bf16(float f) {
-    const uint32_t b = __float_as_uint(f);
-    return (b + 0x7FFFu + ((b >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ uint32_t ksh_obs16_dword(const uint8_t *plane, const uint32_t *pair, int d) {
-    const int sq = (int)((unsigned)d / 23u);
-    const int k = d - 23 * sq;
-    const uint32_t pl = plane[sq];
-    if (k >= 14) return pair[k - 14];
-    return (int)(pl >> 1) == k ? (0x3F80u << ((pl & 1u) * 16u)) : 0u;
-}
-__device__ __forceinline__ void ksh_write_obs16(KshWaveLds &W, const KshStepArgs &a, int g, int lane, int mf_idx, float mf_hint) {
-    const uint8_t *st8 = ST8(W);
-    const int side = st8[S_SIDE];
-    uint8_t *plane = reinterpret_cast<uint8_t *>(W.obsbits);       // [81] plane index of the piece on each POV square, 0xFF = empty
-    uint32_t *pair = W.obsbits + 24;                                // [9] bf16 pairs of planes 28-45
-    if (lane < 24) W.obsbits[lane] = 0xFFFFFFFFu;
-    wave_lds_sync();
-#pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-        const int s = pass * 64 + lane;
-        if (s < 81 && st8[s] != 0) {
-            const int pc = st8[s];
-            const int col = pc >= 15 ? 1 : 0;
-            const int t = pc - 1 - 14 * col;
-            plane[side == 0 ? s : 80 - s] = (uint8_t)((col == side ? 0 : 14) + t);
-        }
-    }
-    ksh_obs_meta(W, a, lane, mf_idx, mf_hint);
-    wave_lds_sync();
-    if (lane < 9) pair[lane] = ksh_obs_bf16(W.metav[2 * lane]) | (ksh_obs_bf16(W.metav[2 * lane + 1]) << 16);
-    wave_lds_sync();
-    uint32_t *orow = reinterpret_cast<uint32_t *>(a.obs) + (size_t)g * KSH_OBS16_DW;   // rows are 4-byte aligned (7 452 B apart)
-    const int head = (int)(((16 - (reinterpret_cast<size_t>(orow) & 15)) & 15) >> 2);
-    const int nfull = (KSH_OBS16_DW - head) >> 2;   // 465 aligned 16-byte chunks
-#pragma unroll
-    for (int it = 0; it < 8; it++) {                // 8 * 64 >= 465
-        const int c = lane + 64 * it;
-        if (c < nfull) {
-            const int d = head + 4 * c;
-            int sq = (int)((unsigned)d / 23u);
-            int k = d - 23 * sq;
-            uint32_t pl = plane[sq];
-            const uint32_t pl_next = plane[sq + 1];  // sq + 1 <= 81: still inside obsbits
-            uint32_t w[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                w[j] = k >= 14 ? pair[k - 14] : ((int)(pl >> 1) == k ? (0x3F80u << ((pl & 1u) * 16u)) : 0u);
-                k++;
-                if (k == 23) { k = 0; pl = pl_next; }
-            }
-            ksh_store16(orow + d, uint4{w[0], w[1], w[2], w[3]});
-        }
-    }
-    if (lane < head) orow[lane] = ksh_obs16_dword(plane, pair, lane);
-    const int tail0 = head + 4 * nfull;
-    if (lane < KSH_OBS16_DW - tail0) orow[tail0 + lane] = ksh_obs16_dword(plane, pair, tail0 + lane);
-}
-
-// Order of one step, chosen around two hardware facts: (1) the kernel is HBM-write bound, so the first
-// observation store must leave as early as possible -- everything it does not need (table staging, move
-// generation) comes after it; (2) on gfx9 loads and stores share one in-order vmcnt, so every global LOAD of
-// a wave (state, action, history, tables) is issued AND consumed before its first observation store.
+// Order of one step, chosen around two hardware facts: (1) the kernel is HBM-write bound at scale, so the
+// observation stores leave as soon as the move is applied, before the move generator runs; (2) on gfx9 loads
+// and stores share one in-order vmcnt, so every global LOAD of a wave (state, action, history, tables) is issued
+// AND consumed before its first observation store.  Since round 3 the tables are staged into LDS first thing (the
+// observation writer reads its expansion tables from there); measured neutral against staging them after the
+// observation (profiles/r03_env_variants.log).
 template <int OBS16, int TABG>
 __device__ __forceinline__ void ksh_env_step_body(const KshStepArgs &a) {
     __shared__ typename KshLdsSel<TABG>::type L;
     const KshTables &T = ksh_tab_of(L, a.tables);
+    const KshLuts &LU = ksh_lut_of(L);
 #ifdef KSH_STAMPS
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -673,15 +731,21 @@ __device__ __forceinline__ void ksh_env_step_body(const KshStepArgs &a) {
         if (lane < 32) st_word = reinterpret_cast<const uint32_t *>(a.state + (size_t)g * 128)[lane];
         if (a.mode == 2) act = a.actions[g];
     }
-    constexpr int NV = (int)(sizeof(KshTables) / 16);   // uint4 count: 6 full rounds of 256 threads + a remainder
+    // table loads are issued now and land in registers while the state is decoded and the move applied; they go to LDS
+    // right before the first consumer (the observation writer's expansion tables)
     constexpr int NT = 64 * KSH_WPB;
+    constexpr int NV = (int)(sizeof(KshTables) / 16);      // the whole block: 6 full rounds of 256 threads + a remainder
+    constexpr int NL = (int)(sizeof(KshLuts) / 16);        // the expansion tables alone: one partial round
     static_assert(NV >= 6 * NT && NV < 7 * NT, "staging below is written for 6 full rounds + a remainder");
+    static_assert(NL <= NT, "one round");
     uint4 t0 = {0u, 0u, 0u, 0u}, t1 = t0, t2 = t0, t3 = t0, t4 = t0, t5 = t0, t6 = t0;
     const bool trem = (int)threadIdx.x < NV - 6 * NT;
     if constexpr (!TABG) {
         const uint4 *tsrc = reinterpret_cast<const uint4 *>(a.tables) + threadIdx.x;
         t0 = tsrc[0]; t1 = tsrc[NT]; t2 = tsrc[2 * NT]; t3 = tsrc[3 * NT]; t4 = tsrc[4 * NT]; t5 = tsrc[5 * NT];
         if (trem) t6 = tsrc[6 * NT];
+    } else {
+        if ((int)threadIdx.x < NL) t0 = reinterpret_cast<const uint4 *>(&a.tables->lut)[threadIdx.x];
     }
 
     int out_done = 0, out_reason = 0, out_winner = -1, n_out = 0;
@@ -689,6 +753,10 @@ __device__ __forceinline__ void ksh_env_step_body(const KshStepArgs &a) {
     float out_reward = 0.0f;
     int me = 0, mover = 0, mc = 0, rep = 1, mf_idx = -1;
     float mf_hint = 0.0f;
+    unsigned long long hv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hkey = 0;   // prefetched history keys / this move's key
+    unsigned long long *hrow = nullptr;
+    int hidx = 0;
+    bool hist_ok = false;
 
     if (live) {
         // ---- state record into LDS, clear the legal bit-set
@@ -702,15 +770,12 @@ __device__ __forceinline__ void ksh_env_step_body(const KshStepArgs &a) {
 
         // ---- history prefetch (step mode): this move appends entry hidx = move_count - base; the first 512
         // earlier entries go to registers now (max_moves = 500 never needs more)
-        const int hidx = (int)(st8[S_MC] | (st8[S_MC + 1] << 8)) - (int)(st8[S_HBASE] | (st8[S_HBASE + 1] << 8));
-        const bool hist_ok = a.mode == 2 && hidx >= 0 && hidx < a.hist_cap;
-        unsigned long long *hrow = a.hist + (size_t)g * (size_t)a.hist_cap;
-        unsigned long long hv[8];
+        hidx = (int)(st8[S_MC] | (st8[S_MC + 1] << 8)) - (int)(st8[S_HBASE] | (st8[S_HBASE + 1] << 8));
+        hist_ok = a.mode == 2 && hidx >= 0 && hidx < a.hist_cap;
+        hrow = a.hist + (size_t)g * (size_t)a.hist_cap;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            hv[k] = 0;
+        for (int k = 0; k < 8; k++)
             if (hist_ok && 64 * k + lane < hidx) hv[k] = hrow[64 * k + lane];
-        }
 
         if (a.mode == 1) {
             const bool rs = a.reset_mask == nullptr || a.reset_mask[g] != 0;
@@ -815,50 +880,65 @@ __device__ __forceinline__ void ksh_env_step_body(const KshStepArgs &a) {
                     me = 1 - mover;
                     moved = true;
                     KSH_STAMP(3);  // move applied + key updated
-                    // ---- append the key to the game's history and count its earlier occurrences
-                    if (hist_ok) {
-                        if (lane == 0) hrow[hidx] = h;
-                        int matches = 0;
-#pragma unroll
-                        for (int k = 0; k < 8; k++) matches += __popcll(__ballot(64 * k + lane < hidx && hv[k] == h));
-                        for (int base = 512; base < hidx; base += 64) {  // bounded: hidx < hist_cap; only for max_moves > 512
-                            const int i = base + lane;
-                            const bool m = (i < hidx) && hrow[i] == h;
-                            matches += __popcll(__ballot(m));
-                        }
-                        rep += matches;
-                    }
-                    KSH_STAMP(4);  // history scanned
-                    // ---- observation of the post-move state: issued NOW so the stores drain while the tables are
-                    // staged and the move generator runs; rewritten below in the rare case the game ends and is reset
-                    if (OBS16) ksh_write_obs16(W, a, g, lane, mf_idx, mf_hint);
-                    else ksh_write_obs(W, a, g, lane, mf_idx, mf_hint);
-                    obs_written = true;
-                    KSH_STAMP(5);  // obs stores issued
+                    hkey = h;
                 }
             }
         }
     }
 
-    // ---- attack tables into LDS (24.9 KB, shared by the block's waves); their loads were issued at the top
+    // ---- tables into LDS (their loads were issued at the top); the only block barrier, reached by every wave
     if constexpr (!TABG) {
         uint4 *tdst = reinterpret_cast<uint4 *>(const_cast<KshTables *>(&T)) + threadIdx.x;
         tdst[0] = t0; tdst[NT] = t1; tdst[2 * NT] = t2; tdst[3 * NT] = t3; tdst[4 * NT] = t4; tdst[5 * NT] = t5;
         if (trem) tdst[6 * NT] = t6;
-        __syncthreads();
+    } else {
+        // attack tables stay in global memory; only the 3.3 KB of expansion tables go to LDS
+        if ((int)threadIdx.x < NL) reinterpret_cast<uint4 *>(const_cast<KshLuts *>(&LU))[threadIdx.x] = t0;
     }
+    __syncthreads();
     if (!live) return;  // wave-uniform
     KSH_STAMP(2);  // tables staged
 
     if (moved) {
+        // ---- append the key to the game's history and count its earlier occurrences (shogi_rules_logic.py:638-695).  The
+        // keys were prefetched at the top; the verdict is only needed for the termination test after the move generator.
+        // Where the scan runs was measured (profiles/r03_env_variants.log, 4096 games): after the generator 24.2 us; between
+        // the observation stores and the generator 24.8 us (loads and stores share one in-order vmcnt, and behind the store
+        // rounds' branches the compiler can only wait with vmcnt(0), i.e. for every store to be acknowledged); before the
+        // observation stores 25.8 us (the keys have not landed yet).  Scanning late keeps 16 registers alive across the
+        // generator (78 VGPRs), which the LDS-table kernel can afford (4 waves per SIMD either way); the global-table
+        // kernel, whose point is 7 waves per SIMD, scans before the generator.
+        auto scan_history = [&]() {
+            if (hist_ok) {
+                if (lane == 0) hrow[hidx] = hkey;
+                int matches = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) matches += __popcll(__ballot(64 * k + lane < hidx && hv[k] == hkey));
+                for (int base = 512; base < hidx; base += 64) {  // bounded: hidx < hist_cap; only for max_moves > 512
+                    const int i = base + lane;
+                    const bool m = (i < hidx) && hrow[i] == hkey;
+                    matches += __popcll(__ballot(m));
+                }
+                rep += matches;
+            }
+        };
+        // ---- observation of the post-move state: issued NOW so that the stores drain while the move generator runs;
+        // rewritten below in the rare case the game ends and is reset
+        if (OBS16) ksh_write_obs16(W, LU, a, g, lane, mf_idx, mf_hint);
+        else ksh_write_obs(W, LU, a, g, lane, mf_idx, mf_hint);
+        obs_written = true;
+        KSH_STAMP(5);  // obs stores issued
+        if constexpr (TABG) scan_history();
         // ---- legal moves of the side now to move (+ nested uchi-fu-zume reply search)
         bool chk;
+        unsigned long long *dbg = nullptr;
 #ifdef KSH_STAMPS
-        int n = ksh_gen_full(T, W, lane, me, chk, a.stamps ? a.stamps + (size_t)g * 32 + 16 : nullptr);
-#else
-        int n = ksh_gen_full(T, W, lane, me, chk);
+        dbg = a.stamps ? a.stamps + (size_t)g * 32 + 16 : nullptr;
 #endif
+        const int n = ksh_gen_full(T, LU, W, lane, me, chk, dbg);
         KSH_STAMP(6);  // movegen done
+        if constexpr (!TABG) scan_history();
+        KSH_STAMP(4);  // history scanned
         need_gen = false;
         n_out = n;
         // ---- termination (shogi_game.py:408-450): no moves -> max moves -> sennichite
@@ -892,7 +972,7 @@ __device__ __forceinline__ void ksh_env_step_body(const KshStepArgs &a) {
 
     if (need_gen) {
         bool chk;
-        int n = ksh_gen_full(T, W, lane, me, chk);
+        int n = ksh_gen_full(T, LU, W, lane, me, chk);
         n_out = n;
         if (a.mode == 3 && st8[S_OVER] != 0) {          // already marked finished: report the stored verdict
             out_done = 1;
@@ -916,8 +996,8 @@ __device__ __forceinline__ void ksh_env_step_body(const KshStepArgs &a) {
 
     // ---- observation, unless it was already issued right after the move
     if (!obs_written) {
-        if (OBS16) ksh_write_obs16(W, a, g, lane, mf_idx, mf_hint);
-        else ksh_write_obs(W, a, g, lane, mf_idx, mf_hint);
+        if (OBS16) ksh_write_obs16(W, LU, a, g, lane, mf_idx, mf_hint);
+        else ksh_write_obs(W, LU, a, g, lane, mf_idx, mf_hint);
     }
     KSH_STAMP(9);
 
@@ -942,19 +1022,21 @@ __device__ __forceinline__ void ksh_env_step_body(const KshStepArgs &a) {
         const int nfull = (KSH_A - head) >> 4;
         const int tail0 = head + 16 * nfull;                     // first byte of the ragged tail
         if (lane < head) mrow[lane] = (uint8_t)((W.maskbits[0] >> lane) & 1u);
+        {
+            // round `it` of lane l covers the 16 actions 1024 ids after round it-1's: the bit-set word index advances by 32,
+            // the shift never changes, and each byte of the 16 bits becomes eight 0/1 bytes through one 8-byte LDS lookup
+            const int b0 = head + 16 * lane;
+            const int sh = b0 & 31;
+            const uint32_t *mw = &W.maskbits[b0 >> 5];
+            const uint2 *b8 = reinterpret_cast<const uint2 *>(LU.byte8);
+            uint8_t *m0 = mrow + b0;
 #pragma unroll
-        for (int it = 0; it < 14; it++) {                         // 14 * 64 >= 845: constant trip count
-            const int c = lane + 64 * it;
-            if (c < nfull) {
-                const int b0 = head + 16 * c;
-                const uint32_t lo = W.maskbits[b0 >> 5], hi = W.maskbits[(b0 >> 5) + 1];
-                const uint32_t x = __funnelshift_r(lo, hi, b0 & 31);  // 32 bits starting at bit b0
-                uint4 v;
-                v.x = __umul24(x & 0xFu, 0x204081u) & 0x01010101u;    // 4 bits -> 4 bytes of 0/1
-                v.y = __umul24((x >> 4) & 0xFu, 0x204081u) & 0x01010101u;
-                v.z = __umul24((x >> 8) & 0xFu, 0x204081u) & 0x01010101u;
-                v.w = __umul24((x >> 12) & 0xFu, 0x204081u) & 0x01010101u;
-                ksh_store16(mrow + b0, v);
+            for (int it = 0; it < 14; it++) {                     // 14 * 64 >= 845: constant trip count
+                if (lane + 64 * it < nfull) {
+                    const uint32_t x = __funnelshift_r(mw[32 * it], mw[32 * it + 1], sh);  // 32 bits starting at this chunk's first id
+                    const uint2 lo = b8[x & 0xFFu], hi = b8[(x >> 8) & 0xFFu];
+                    ksh_store16(m0 + 1024 * it, uint4{lo.x, lo.y, hi.x, hi.y});
+                }
             }
         }
         const int ntail = KSH_A - tail0;

@@ -13,11 +13,23 @@
 #include <stdint.h>
 #include <string.h>
 
+// Small expansion tables, always staged into LDS (3.3 KB).  The env kernel is bound by its VALU instruction count at the
+// 4096-game size, while the LDS pipe is nearly idle: every bit -> byte / bit -> float /
+// bit-interleave expansion that used to be shifts, multiplies and selects is one LDS lookup.
+struct KshLuts {
+    uint32_t byte8[256][2];    // byte b -> eight bytes, byte i = bit i of b                  (legal-mask row: bits -> bool bytes)
+    uint32_t nib_f32[16][4];   // nibble n -> four float32 words, word i = bit i ? 1.0f : 0.0f (observation planes 0-27)
+    uint32_t spread8[256];     // byte b -> 16 bits with bit i of b at position 2i            (non-promoting / promoting ids interleave)
+    float hand18[20];          // c -> (float)((double)c / 18.0): hand-count planes (shogi_game_io.py:513-527), c = 0..19
+};
+static_assert(sizeof(KshLuts) % 16 == 0, "staged as uint4");
+
 struct KshTables {
     uint32_t ray[8][81][4];    // [dir][sq] -> {w0,w1,w2,0}: squares from sq (exclusive) to the edge
     uint32_t step[11][81][4];  // [class][sq] -> {w0,w1,w2,0}
     uint8_t init_state[128];   // packed initial position (shogi_game.py:79-130)
     uint8_t pad[16];
+    KshLuts lut;               // last member: the table-less kernel variant stages only this part
 };
 static_assert(sizeof(KshTables) % 16 == 0, "tables are copied to LDS as uint4");
 
@@ -64,8 +76,26 @@ static inline void ksh_finish_record(uint8_t *rec, int max_moves) {
 
 static inline void ksh_bb_set(uint32_t *w, int sq) { w[sq / 27] |= 1u << (sq % 27); }
 
+static inline void ksh_build_luts(KshLuts *u) {
+    for (int b = 0; b < 256; b++) {
+        uint32_t lo = 0, hi = 0, sp = 0;
+        for (int i = 0; i < 4; i++) {
+            lo |= (uint32_t)((b >> i) & 1) << (8 * i);
+            hi |= (uint32_t)((b >> (4 + i)) & 1) << (8 * i);
+        }
+        for (int i = 0; i < 8; i++) sp |= (uint32_t)((b >> i) & 1) << (2 * i);
+        u->byte8[b][0] = lo;
+        u->byte8[b][1] = hi;
+        u->spread8[b] = sp;
+    }
+    for (int n = 0; n < 16; n++)
+        for (int i = 0; i < 4; i++) u->nib_f32[n][i] = ((n >> i) & 1) ? 0x3F800000u : 0u;
+    for (int c = 0; c < 20; c++) u->hand18[c] = (float)((double)c / 18.0);
+}
+
 static inline void ksh_build_tables(KshTables *t) {
     memset(t, 0, sizeof(*t));
+    ksh_build_luts(&t->lut);
     static const int DR[8] = {-1, 1, 0, 0, -1, 1, -1, 1};
     static const int DC[8] = {0, 0, -1, 1, -1, 1, 1, -1};
     for (int d = 0; d < 8; d++)

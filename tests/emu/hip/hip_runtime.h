@@ -21,6 +21,7 @@
 #define __restrict__
 
 struct uint4 { uint32_t x, y, z, w; };
+struct uint2 { uint32_t x, y; };
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }

@@ -31,8 +31,8 @@ for t in range(80):
     env.step(a, validate=False)
 st = torch.zeros(N, 32, dtype=torch.int64, device="cuda:0")
 L.ksh_debug_set_stamps(st.data_ptr())
-order = [0, 1, 3, 4, 5, 2, 6, 7, 9, 10]
-names = ["entry", "state in LDS", "applied+key", "history", "obs stores", "tables+barrier", "movegen", "term/regen", "late obs", "mask stores"]
+order = [0, 1, 3, 2, 5, 6, 4, 7, 9, 10]      # stamp ids in the order the kernel passes them (round 3 phase order)
+names = ["entry", "state in LDS", "applied+key", "tables+barrier", "obs stores", "movegen", "history", "term/regen", "late obs", "mask stores"]
 acc = np.zeros((9,), np.float64)
 gacc = np.zeros((7,), np.float64)
 nested = 0.0
@@ -49,7 +49,7 @@ for t in range(reps):
     acc += np.median(d, axis=0)
     gs = s[ok]
     # inside the first move generation: stamps 16+11..16+15, end of main gen at 16+10, flag nested at 16+9
-    seq = np.stack([gs[:, 2], gs[:, 27], gs[:, 28], gs[:, 29], gs[:, 30], gs[:, 31], gs[:, 26], gs[:, 6]], axis=1)
+    seq = np.stack([gs[:, 5], gs[:, 27], gs[:, 28], gs[:, 29], gs[:, 30], gs[:, 31], gs[:, 26], gs[:, 6]], axis=1)
     gacc += np.median(np.diff(seq, axis=1), axis=0)
     nested += gs[:, 25].mean()
     span += (s[:, 10].max() - s[:, 0].min())
