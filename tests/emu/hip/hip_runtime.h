@@ -121,6 +121,7 @@ struct bf16 {
 #define __builtin_amdgcn_readfirstlane(x) (__shfl((int)(x), 0))
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_readlane(x, l) (__shfl((int)(x), (l)))
