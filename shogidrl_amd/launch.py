@@ -43,8 +43,9 @@ def free_port():
     return p
 
 
-def visible_gpus(timeout=180):
-    """Number of GPUs a fresh process of this interpreter sees.  Counted in a CHILD process: whatever
+def visible_gpus(timeout=600):
+    """Number of GPUs a fresh process of this interpreter sees, or None when it could not be counted (the child failed or
+    took longer than `timeout`: the first `import torch` on a cold box can take minutes).  Counted in a CHILD process: whatever
     torch.cuda.device_count() has to initialise to answer (amdsmi, or HIP itself when amdsmi is missing) is gone when the
     child exits; this process stays free of any GPU runtime state.  The visibility masks the child inherits
     (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES) are honoured by construction."""
@@ -52,14 +53,14 @@ def visible_gpus(timeout=180):
     try:
         r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout)
     except (OSError, subprocess.TimeoutExpired):
-        return 0
+        return None
     for line in r.stdout.decode(errors="replace").splitlines():
         if line.startswith("KSH_GPUS="):
             try:
                 return int(line[len("KSH_GPUS="):])
             except ValueError:
-                return 0
-    return 0
+                return None
+    return None
 
 
 def per_rank_miopen_env(local_rank, base=None):
@@ -85,7 +86,11 @@ def spawn_ranks(argv, n_ranks, timeout=None, require_gpus=True, extra_env=None):
     sharing = os.environ.get("KSH_ALLOW_GPU_SHARING") == "1"
     if require_gpus and not sharing:
         have = visible_gpus()
-        if have < n_ranks:
+        if have is None:
+            # not a refusal: every rank checks LOCAL_RANK against the devices it sees (parallel.init_from_env) and fails loudly
+            print("launch: could not count the GPUs beforehand; starting %d ranks, each of which checks its own device" % n_ranks,
+                  file=sys.stderr, flush=True)
+        elif have < n_ranks:
             print("launch: %d ranks requested but only %d GPU(s) visible; refusing to run fewer ranks than asked "
                   "(set KSH_ALLOW_GPU_SHARING=1 with KSH_DIST_BACKEND=gloo to rehearse on a shared GPU)" % (n_ranks, have),
                   file=sys.stderr, flush=True)
