@@ -785,7 +785,8 @@ def supervisor_main(args):
         out["ppo_reference_minibatch64"]["hipgraph_replay"] = _run_side(tail, {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": "0"}, 300)
     emit(out)
     need = ["value", "roofline"] + (["cpu_baseline"] if args.gpus == 1 and not args.no_cpu_baseline else [])
-    return 0 if all(k in out for k in need) else (rc if rc > 0 else 1)
+    good = lambda k: k in out and not (isinstance(out[k], dict) and "error" in out[k])   # (a figure that raised is not a figure)
+    return 0 if all(good(k) for k in need) else (rc if rc > 0 else 1)
 
 
 def main():
