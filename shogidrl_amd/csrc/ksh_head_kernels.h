@@ -920,84 +920,418 @@ struct KshGemmArgs {
     float *Cpart;
 };
 
-#define KSH_GEMM_BM 64
 #define KSH_GEMM_BK 16
+// block tiles of the three products (rows x columns): see ksh_head_gemm_kernel
+#define KSH_GEMM_M0 64    // mode 0 (logits):  B x 13527
+#define KSH_GEMM_N0 128
+#define KSH_GEMM_M1 128   // mode 1 (dfeat):   B x K, reduction over the 13 527 actions split KSH_HEAD_KSPLIT ways
+#define KSH_GEMM_N1 192
+#define KSH_GEMM_M2 64    // mode 2 (dW):      13527 x (K + 1), reduction over the samples
+#define KSH_GEMM_N2 192
 
-extern "C" __global__ void __launch_bounds__(256) ksh_head_gemm_kernel(KshGemmArgs g) {
-    __shared__ float As[KSH_GEMM_BK][KSH_GEMM_BM];
-    __shared__ float Bs[KSH_GEMM_BK][KSH_GEMM_BM];
+struct __attribute__((packed, aligned(4))) ksh_f4a4 {   // four floats at a dword-aligned address (gfx9: global_load_dwordx4 needs no more)
+    float x, y, z, w;
+};
+// Floats [o0, o0 + 4) of the tensor at `base` (offsets in floats), of which only those below `run_end` (the end of the row /
+// reduction range they belong to) count: the others read as zero, and `ok == false` gives four zeros.  ONE unconditional
+// 16-byte load and bit masks, no branch (the first version had an `if` per case: the compiler turned the tile loader into 297
+// scalar loads, each behind its own `s_waitcnt vmcnt(0)`).  The load never leaves the tensor (`tensor_end` floats, >= 4): a
+// quad that would is fetched as the tensor's last quad and shifted into place.
+__device__ __forceinline__ ksh_f4a4 ksh_gemm_ld4_raw(const float *base, long long o0, long long tensor_end) {
+    const long long oc = o0 < tensor_end - 4 ? o0 : tensor_end - 4;
+    return *reinterpret_cast<const ksh_f4a4 *>(base + oc);
+}
+// (the masking half, applied when the quad is written to LDS -- AFTER the MFMAs of the step the load overlapped)
+__device__ __forceinline__ float4 ksh_gemm_ld4_fix(ksh_f4a4 v, long long o0, long long run_end, long long tensor_end, bool ok) {
+    const long long oc = o0 < tensor_end - 4 ? o0 : tensor_end - 4;
+    const long long dl = o0 - oc;
+    const int d = dl > 4 ? 4 : (int)dl;                     // 0: in place; 1..3: shifted; 4: nothing of the quad is wanted
+    const uint32_t x = __float_as_uint(v.x), y = __float_as_uint(v.y), z = __float_as_uint(v.z), w = __float_as_uint(v.w);
+    const uint32_t m0 = d == 0 ? 0xFFFFFFFFu : 0u, m1 = d == 1 ? 0xFFFFFFFFu : 0u, m2 = d == 2 ? 0xFFFFFFFFu : 0u,
+                   m3 = d == 3 ? 0xFFFFFFFFu : 0u;
+    const long long left = ok ? run_end - o0 : 0;           // how many of the four floats count
+    const uint32_t k0 = left > 0 ? 0xFFFFFFFFu : 0u, k1 = left > 1 ? 0xFFFFFFFFu : 0u, k2 = left > 2 ? 0xFFFFFFFFu : 0u,
+                   k3 = left > 3 ? 0xFFFFFFFFu : 0u;
+    return make_float4(ksh_u2f(((x & m0) | (y & m1) | (z & m2) | (w & m3)) & k0), ksh_u2f(((y & m0) | (z & m1) | (w & m2)) & k1),
+                       ksh_u2f(((z & m0) | (w & m1)) & k2), ksh_u2f((w & m0) & k3));
+}
+
+// Round 3: the tile kernel rewritten for the matrix cores' sake -- BM x BN block tile (128x128 / 128x192 / 64x192), four waves
+// as 2 x 2 with (BM/64) x (BN/64) accumulator tiles of 32x32 each, K-step 16, DOUBLE-BUFFERED LDS (the next step's global loads
+// are in flight during this step's MFMAs, one barrier per step), 16-byte global loads along whichever index of an operand is
+// contiguous (AKF / BKF: the reduction index k is; else the row / column index is).  LDS holds As[k][m] / Bs[k][n] with a
+// 4-float pad: an MFMA operand read is 32 consecutive words per k (conflict-free), an m- or n-contiguous quad is one 16-byte
+// write, a k-contiguous quad four scalar writes.
+template <int MODE, int BM, int BN, int AKF, int BKF>
+__device__ __forceinline__ void ksh_head_gemm_body(const KshGemmArgs &g) {
+    constexpr int BK = KSH_GEMM_BK, LDA = BM + 4, LDB = BN + 4;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int CA = BM * BK / 4 / 256, CB = BN * BK / 4 / 256;     // 16-byte chunks per thread and K-step
+    static_assert(BM % 64 == 0 && BN % 64 == 0 && CA >= 1 && CB >= 1, "tile shape");
+    __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
     __shared__ int s_any;
-    if (*g.n_over == 0u) return;                           // no dense row in this minibatch (the production case)
+    __shared__ int s_nact, s_wtot[4];
+    __shared__ unsigned short s_steps[512];                 // mode 2: the K-steps that hold a flagged sample, ascending
     const int t = (int)threadIdx.x, lane = t & 63, w = t >> 6;
-    const int wm = w >> 1, wn = w & 1;
-    const int m0 = (int)blockIdx.x * KSH_GEMM_BM, n0 = (int)blockIdx.y * KSH_GEMM_BM;
-    if (g.mode != 2) {                                     // any flagged row in this row tile?
+    const int wm = w >> 1, wn = w & 1, r = lane & 31, h = lane >> 5;
+    const int m0 = (int)blockIdx.x * BM, n0 = (int)blockIdx.y * BN;
+    if (MODE != 2) {                                     // any flagged row in this row tile?
         if (t == 0) s_any = 0;
         __syncthreads();
-        if (t < KSH_GEMM_BM && m0 + t < g.M && g.flags[(size_t)(m0 + t) * 8] != 0.0f) s_any = 1;
+        if (t < BM && m0 + t < g.M && g.flags[(size_t)(m0 + t) * 8] != 0.0f) s_any = 1;
         __syncthreads();
         if (!s_any) return;
     }
-    ksh_f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
-    const bool a_kfast = g.sAk == 1, b_kfast = g.sBk == 1;
-    bool contributed = false;
     const bool split = g.ksplit > 1;
     const int kbeg = split ? (int)blockIdx.z * g.kchunk : 0;
     const int kend = split ? ((kbeg + g.kchunk < g.Kd) ? kbeg + g.kchunk : g.Kd) : g.Kd;
-    for (int k0 = kbeg; k0 < kend; k0 += KSH_GEMM_BK) {
-        if (g.mode == 2) {                                 // the reduction runs over sample rows: skip steps without a dense one
-            __syncthreads();
-            if (t == 0) s_any = 0;
-            __syncthreads();
-            if (t < KSH_GEMM_BK && k0 + t < g.Kd && g.flags[(size_t)(k0 + t) * 8] != 0.0f) s_any = 1;
-            __syncthreads();
-            if (!s_any) continue;                          // block-uniform
-            contributed = true;
-        } else {
-            __syncthreads();
-        }
+    const int total_steps = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+    ksh_f32x16 acc[TM][TN];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            int kk, i;
-            if (a_kfast) { kk = t & 15; i = (t >> 4) + 16 * q; } else { i = t & 63; kk = (t >> 6) + 4 * q; }
-            const int m = m0 + i, k = k0 + kk;
-            float v = 0.0f;
-            if (m < g.M && k < kend && (g.mode != 2 || g.flags[(size_t)k * 8] != 0.0f)) v = g.A[(long long)m * g.sAm + (long long)k * g.sAk];
-            As[kk][i] = v;
-            if (b_kfast) { kk = t & 15; i = (t >> 4) + 16 * q; } else { i = t & 63; kk = (t >> 6) + 4 * q; }
-            const int n = n0 + i;
-            const int kb = k0 + kk;
-            v = 0.0f;
-            if (n < g.N && kb < kend) v = (g.mode == 2 && n == g.N - 1) ? 1.0f : g.Bm[(long long)kb * g.sBk + (long long)n * g.sBn];
-            Bs[kk][i] = v;
-        }
-        __syncthreads();
+    for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int kk = 0; kk < KSH_GEMM_BK; kk += 2) {
-            const float av = As[kk + (lane >> 5)][32 * wm + (lane & 31)];
-            const float bv = Bs[kk + (lane >> 5)][32 * wn + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[i][j][q] = 0.0f;
+    // ---- global -> registers for the K-step that starts at k0 (rows / steps beyond the operand are clamped to a valid row and
+    // masked to zero, so every lane issues the same unconditional loads)
+    const long long endA = AKF ? (long long)(g.M - 1) * g.sAm + g.Kd : (long long)(g.Kd - 1) * g.sAk + g.M;
+    const int ncolB = MODE == 2 ? g.N - 1 : g.N;           // columns B really has (mode 2: column N-1 is the constant 1)
+    const long long endB = BKF ? (long long)(g.N - 1) * g.sBn + g.Kd : (long long)(g.Kd - 1) * g.sBk + ncolB;
+    // operand quad q of this thread: where it lives (float offset), where its run ends, whether it counts at all
+    auto a_quad = [&](int q, int k0, long long &o0, long long &run_end, bool &ok) {
+        const int c = t + 256 * q;
+        if (AKF) {                                         // rows of A are contiguous in k: chunk = (row i, four k)
+            const int i = c / (BK / 4), kq = (c - i * (BK / 4)) * 4, m = m0 + i;
+            const long long row = (long long)(m < g.M ? m : g.M - 1) * g.sAm;
+            o0 = row + k0 + kq; run_end = row + kend; ok = m < g.M;
+        } else {                                           // A is contiguous in m: chunk = (one k, four rows)
+            const int kk = c / (BM / 4), mq = (c - kk * (BM / 4)) * 4, k = k0 + kk;
+            const int kc = k < kend ? k : kend - 1;
+            const long long row = (long long)kc * g.sAk;
+            o0 = row + m0 + mq; run_end = row + g.M; ok = k < kend;
+        }
+    };
+    auto b_quad = [&](int q, int k0, long long &o0, long long &run_end, bool &ok) {
+        const int c = t + 256 * q;
+        if (BKF) {                                         // B[k][n] with k contiguous (W rows in mode 0)
+            const int i = c / (BK / 4), kq = (c - i * (BK / 4)) * 4, n = n0 + i;
+            const long long row = (long long)(n < g.N ? n : g.N - 1) * g.sBn;
+            o0 = row + k0 + kq; run_end = row + kend; ok = n < g.N;
+        } else {                                           // contiguous in n
+            const int kk = c / (BN / 4), nq = (c - kk * (BN / 4)) * 4, k = k0 + kk;
+            const int kc = k < kend ? k : kend - 1;
+            const long long row = (long long)kc * g.sBk;
+            o0 = row + n0 + nq; run_end = row + ncolB; ok = k < kend;
+        }
+    };
+    // two register sets for operand quads in flight: a step's loads are issued TWO steps before its MFMAs (one step did not
+    // cover the latency of memory: with one wave per SIMD the dW product spent 2.6 k of 4.1 k cycles per step waiting)
+    ksh_f4a4 ra0[CA], rb0[CB], ra1[CA], rb1[CB], rat[CA], rbt[CB];   // (t: the range's last step, loaded first, used last)
+    float fa0[CA], fa1[CA], fat[CA];                                // mode 2: the flag of the sample row an A quad belongs to
+    // What does not change from one K-step to the next is computed ONCE per thread: the address of each of its quads at
+    // k = kbeg (rows clamped to the operand), and four keep-bits per quad (row / column validity).  An INTERIOR step (all of
+    // its k below kend - the block-uniform case for every step but the last) is then: pointer + k0 * stride, one 16-byte
+    // load, four ANDs at staging time.  Only the last step of a reduction range goes through the general quad logic above
+    // (k tail, end-of-tensor clamp).  (PMC, first tiled version: 300 VALU instructions per K-step and wave for this
+    // bookkeeping against 32-48 MFMAs -- the matrix pipe was 30-40 % busy.)
+    const float *pa[CA], *pb[CB];
+    uint32_t keepa[CA], keepb[CB];
+#pragma unroll
+    for (int q = 0; q < CA; q++) {
+        long long o0, re; bool ok;
+        a_quad(q, kbeg, o0, re, ok);
+        pa[q] = g.A + o0;
+        if (AKF) keepa[q] = ok ? 15u : 0u;
+        else {
+            const long long left = re - o0;                // valid rows m in this quad
+            keepa[q] = left >= 4 ? 15u : (left <= 0 ? 0u : ((1u << (int)left) - 1u));
         }
     }
-    if (g.mode == 2 && !contributed) return;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int m = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int n = n0 + 32 * wn + (lane & 31);
-        if (m >= g.M || n >= g.N) continue;
-        if (split) {            // partial tile of this reduction slice (every row of a tile that holds a flagged row)
-            g.Cpart[((size_t)blockIdx.z * (size_t)g.M + (size_t)m) * (size_t)g.N + (size_t)n] = acc[r];
-            continue;
-        }
-        if (g.mode == 2) {
-            if (n == g.N - 1) { if (g.C2 != nullptr) g.C2[m] += acc[r]; }
-            else g.C[(long long)m * g.sCm + n] += acc[r];
-        } else if (g.flags[(size_t)m * 8] != 0.0f) {
-            g.C[(long long)m * g.sCm + n] = acc[r] + (g.bias != nullptr ? g.bias[n] : 0.0f);
+    for (int q = 0; q < CB; q++) {
+        long long o0, re; bool ok;
+        b_quad(q, kbeg, o0, re, ok);
+        pb[q] = g.Bm + o0;
+        if (BKF) keepb[q] = ok ? 15u : 0u;
+        else {
+            const long long left = re - o0;
+            keepb[q] = left >= 4 ? 15u : (left <= 0 ? 0u : ((1u << (int)left) - 1u));
         }
     }
+    const long long ska = AKF ? 1 : g.sAk, skb = BKF ? 1 : g.sBk;   // float stride of one k
+    auto keep4 = [](ksh_f4a4 v, uint32_t keep) {
+        const uint32_t m0 = 0u - (keep & 1u), m1 = 0u - ((keep >> 1) & 1u), m2 = 0u - ((keep >> 2) & 1u), m3 = 0u - ((keep >> 3) & 1u);
+        return make_float4(ksh_u2f(__float_as_uint(v.x) & m0), ksh_u2f(__float_as_uint(v.y) & m1), ksh_u2f(__float_as_uint(v.z) & m2),
+                           ksh_u2f(__float_as_uint(v.w) & m3));
+    };
+    // ---- interior K-steps: global -> registers (pointer + k0 * stride, one 16-byte load per quad) ...
+    auto load_fast = [&](ksh_f4a4 (&ra)[CA], ksh_f4a4 (&rb)[CB], float (&fa)[CA], int k0) {
+        const long long dk = (long long)(k0 - kbeg);
+#pragma unroll
+        for (int q = 0; q < CA; q++) {
+            ra[q] = *reinterpret_cast<const ksh_f4a4 *>(pa[q] + dk * ska);
+            if (MODE == 2) fa[q] = g.flags[(size_t)(k0 + (t + 256 * q) / (BM / 4)) * 8];
+        }
+#pragma unroll
+        for (int q = 0; q < CB; q++) rb[q] = *reinterpret_cast<const ksh_f4a4 *>(pb[q] + dk * skb);
+    };
+    // ... and registers -> LDS buffer `buf` (four ANDs per quad; first touched AFTER the MFMAs the loads overlapped)
+    auto stage_fast = [&](ksh_f4a4 (&ra)[CA], ksh_f4a4 (&rb)[CB], float (&fa)[CA], int buf) {
+#pragma unroll
+        for (int q = 0; q < CA; q++) {
+            const int c = t + 256 * q;
+            const float4 v = keep4(ra[q], (MODE == 2 && fa[q] == 0.0f) ? 0u : keepa[q]);
+            if (AKF) {
+                const int i = c / (BK / 4), kq = (c - i * (BK / 4)) * 4;
+                As[buf][kq][i] = v.x; As[buf][kq + 1][i] = v.y; As[buf][kq + 2][i] = v.z; As[buf][kq + 3][i] = v.w;
+            } else {
+                const int kk = c / (BM / 4), mq = (c - kk * (BM / 4)) * 4;
+                *reinterpret_cast<float4 *>(&As[buf][kk][mq]) = v;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < CB; q++) {
+            const int c = t + 256 * q;
+            float4 v = keep4(rb[q], keepb[q]);
+            if (BKF) {
+                const int i = c / (BK / 4), kq = (c - i * (BK / 4)) * 4;
+                Bs[buf][kq][i] = v.x; Bs[buf][kq + 1][i] = v.y; Bs[buf][kq + 2][i] = v.z; Bs[buf][kq + 3][i] = v.w;
+            } else {
+                const int kk = c / (BN / 4), nq = (c - kk * (BN / 4)) * 4, n = n0 + nq;
+                if (MODE == 2) {                           // column N-1 is the constant 1 (-> dbias)
+                    v.x = n == g.N - 1 ? 1.0f : v.x; v.y = n + 1 == g.N - 1 ? 1.0f : v.y;
+                    v.z = n + 2 == g.N - 1 ? 1.0f : v.z; v.w = n + 3 == g.N - 1 ? 1.0f : v.w;
+                }
+                *reinterpret_cast<float4 *>(&Bs[buf][kk][nq]) = v;
+            }
+        }
+    };
+    // ---- the LAST step of a reduction range (k tail, end-of-tensor clamp): the general quad logic, once per block
+    auto load_gen = [&](ksh_f4a4 (&ra)[CA], ksh_f4a4 (&rb)[CB], float (&fa)[CA], int k0) {
+#pragma unroll
+        for (int q = 0; q < CA; q++) {
+            long long o0, re; bool ok;
+            a_quad(q, k0, o0, re, ok);
+            ra[q] = ksh_gemm_ld4_raw(g.A, o0, endA);
+            if (MODE == 2) {
+                const int k = k0 + (t + 256 * q) / (BM / 4);
+                fa[q] = g.flags[(size_t)(k < kend ? k : kend - 1) * 8];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < CB; q++) {
+            long long o0, re; bool ok;
+            b_quad(q, k0, o0, re, ok);
+            rb[q] = ksh_gemm_ld4_raw(g.Bm, o0, endB);
+        }
+    };
+    auto stage_gen = [&](ksh_f4a4 (&ra)[CA], ksh_f4a4 (&rb)[CB], float (&fa)[CA], int buf, int k0) {
+#pragma unroll
+        for (int q = 0; q < CA; q++) {
+            const int c = t + 256 * q;
+            long long o0, re; bool ok;
+            a_quad(q, k0, o0, re, ok);
+            if (MODE == 2) ok = ok && fa[q] != 0.0f;
+            const float4 v = ksh_gemm_ld4_fix(ra[q], o0, re, endA, ok);
+            if (AKF) {
+                const int i = c / (BK / 4), kq = (c - i * (BK / 4)) * 4;
+                As[buf][kq][i] = v.x; As[buf][kq + 1][i] = v.y; As[buf][kq + 2][i] = v.z; As[buf][kq + 3][i] = v.w;
+            } else {
+                const int kk = c / (BM / 4), mq = (c - kk * (BM / 4)) * 4;
+                *reinterpret_cast<float4 *>(&As[buf][kk][mq]) = v;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < CB; q++) {
+            const int c = t + 256 * q;
+            long long o0, re; bool ok;
+            b_quad(q, k0, o0, re, ok);
+            float4 v = ksh_gemm_ld4_fix(rb[q], o0, re, endB, ok);
+            if (BKF) {
+                const int i = c / (BK / 4), kq = (c - i * (BK / 4)) * 4;
+                Bs[buf][kq][i] = v.x; Bs[buf][kq + 1][i] = v.y; Bs[buf][kq + 2][i] = v.z; Bs[buf][kq + 3][i] = v.w;
+            } else {
+                const int kk = c / (BN / 4), nq = (c - kk * (BN / 4)) * 4, n = n0 + nq;
+                if (MODE == 2) {
+                    const float one = ok ? 1.0f : 0.0f;
+                    v.x = n == g.N - 1 ? one : v.x; v.y = n + 1 == g.N - 1 ? one : v.y;
+                    v.z = n + 2 == g.N - 1 ? one : v.z; v.w = n + 3 == g.N - 1 ? one : v.w;
+                }
+                *reinterpret_cast<float4 *>(&Bs[buf][kk][nq]) = v;
+            }
+        }
+    };
+    bool contributed = false;
+    // the K-steps are walked in windows of 512 (the capacity of the step list; one window unless mode 2 reduces over more
+    // than 8192 samples)
+    for (int win = 0; win < total_steps; win += 512) {
+        int nsteps = total_steps - win < 512 ? total_steps - win : 512;
+        if (MODE == 2) {
+            // the reduction runs over sample rows: only the steps with a flagged (dense) one take part, in ascending order
+            // (the order of the float32 sums is fixed).  Ordered compaction: ballot + prefix inside a wave, wave totals
+            // through LDS.
+            __syncthreads();
+            if (t == 0) s_nact = 0;
+            __syncthreads();
+            for (int base = 0; base < nsteps; base += 256) {
+                const int sidx = base + t;
+                bool any = false;
+                if (sidx < nsteps)
+                    for (int j = 0; j < BK; j++) {
+                        const int k = kbeg + (win + sidx) * BK + j;
+                        if (k < kend && g.flags[(size_t)k * 8] != 0.0f) any = true;
+                    }
+                const unsigned long long bal = __ballot(any);
+                if (lane == 0) s_wtot[w] = __popcll(bal);
+                __syncthreads();
+                int off = s_nact;
+                for (int q = 0; q < w; q++) off += s_wtot[q];
+                if (any) s_steps[off + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)sidx;
+                __syncthreads();
+                if (t == 0) s_nact += s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+                __syncthreads();
+            }
+            nsteps = s_nact;
+            if (nsteps == 0) continue;                     // block-uniform: nothing to add from this window
+        }
+        contributed = true;
+        auto step_k0 = [&](int sidx) { return kbeg + (win + (MODE == 2 ? (int)s_steps[sidx] : sidx)) * BK; };
+        // one K-step out of LDS buffer `buf`: operand fragments are read one group (two k-pairs) AHEAD of the MFMAs that use
+        // them, into registers of their own
+        auto mfma_step = [&](int buf) {
+            constexpr int NG = BK / 4;                             // groups of two k-pairs
+            float av[2][2][TM], bv[2][2][TN];
+            auto frags = [&](int gi, int slot) {
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const int kk = 4 * gi + 2 * p + h;
+#pragma unroll
+                    for (int i = 0; i < TM; i++) av[slot][p][i] = As[buf][kk][wm * WM + 32 * i + r];
+#pragma unroll
+                    for (int j = 0; j < TN; j++) bv[slot][p][j] = Bs[buf][kk][wn * WN + 32 * j + r];
+                }
+            };
+            frags(0, 0);
+#pragma unroll
+            for (int gi = 0; gi < NG; gi++) {
+                if (gi + 1 < NG) frags(gi + 1, (gi + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);                 // (keeps the reads above ahead of the MFMAs below)
+#pragma unroll
+                for (int p = 0; p < 2; p++)
+#pragma unroll
+                    for (int i = 0; i < TM; i++)
+#pragma unroll
+                        for (int j = 0; j < TN; j++)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[gi & 1][p][i], bv[gi & 1][p][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // schedule: the range's last step (the only one that may need the general quad logic) is loaded first and multiplied
+        // last; the interior steps run two deep: step s computes from LDS buffer s & 1 while the quads of step s+1 sit in
+        // register set (s+1) & 1 and the loads of step s+2 are issued into set s & 1 (whose step is already in LDS)
+        const bool has_tail = step_k0(nsteps - 1) + BK >= kend;    // block-uniform
+        const int nfast = nsteps - (has_tail ? 1 : 0);
+        if (has_tail) load_gen(rat, rbt, fat, step_k0(nsteps - 1));
+        if (nfast > 0) {
+            load_fast(ra0, rb0, fa0, step_k0(0));
+            stage_fast(ra0, rb0, fa0, 0);
+            if (nfast > 1) load_fast(ra1, rb1, fa1, step_k0(1));
+            __syncthreads();
+            for (int sidx = 0; sidx < nfast; sidx += 2) {
+                if (sidx + 2 < nfast) load_fast(ra0, rb0, fa0, step_k0(sidx + 2));
+                mfma_step(0);
+                __builtin_amdgcn_sched_barrier(0);                 // the quads of step sidx+1 are first touched below this line
+                if (sidx + 1 < nfast) stage_fast(ra1, rb1, fa1, 1);    // (buffer 1 was last read in step sidx-1)
+                __syncthreads();
+                if (sidx + 1 >= nfast) break;
+                if (sidx + 3 < nfast) load_fast(ra1, rb1, fa1, step_k0(sidx + 3));
+                mfma_step(1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (sidx + 2 < nfast) stage_fast(ra0, rb0, fa0, 0);
+                __syncthreads();
+            }
+        }
+        if (has_tail) {
+            stage_gen(rat, rbt, fat, 0, step_k0(nsteps - 1));      // (every wave has left the buffers: the loop ends with a barrier)
+            __syncthreads();
+            mfma_step(0);
+            __syncthreads();
+        }
+    }
+    if (MODE == 2 && !contributed && !split) return;       // (a split slice always writes its partial tile: zeros when it added nothing)
+    // ---- epilogue: register q of a 32x32 tile is row (q & 3) + 8 (q >> 2) + 4 h, column r.  Everything an element needs
+    // from memory (its row's flag, its column's bias, the old value it is added to) is loaded in BATCHES before the stores of
+    // a tile: a load per element in the store loop is 64 round trips to memory per lane (the first version spent more time
+    // there than in its MFMAs).
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int mb = m0 + wm * WM + 32 * i + 4 * h;
+        float fl[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int m = mb + (q & 3) + 8 * (q >> 2);
+            fl[q] = g.flags[(size_t)(m < g.M ? m : g.M - 1) * 8];   // (unconditional: 16 loads in flight, one wait)
+            if (split || MODE == 2) fl[q] = 1.0f;
+        }
+        uint32_t okrow = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) okrow |= ((mb + (q & 3) + 8 * (q >> 2) < g.M && fl[q] != 0.0f) ? 1u : 0u) << q;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int n = n0 + wn * WN + 32 * j + r;
+            const bool nok = n < g.N;
+            if (split) {            // partial tile of this reduction slice (every row of a tile that holds a flagged row)
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int m = mb + (q & 3) + 8 * (q >> 2);
+                    if (nok && ((okrow >> q) & 1u))
+                        g.Cpart[((size_t)blockIdx.z * (size_t)g.M + (size_t)m) * (size_t)g.N + (size_t)n] = acc[i][j][q];
+                }
+            } else if (MODE == 2) {
+                const bool last = n == g.N - 1;          // the constant-1 column: dbias
+                float old[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int m = mb + (q & 3) + 8 * (q >> 2);
+                    old[q] = 0.0f;
+                    if (nok && ((okrow >> q) & 1u)) old[q] = last ? (g.C2 != nullptr ? g.C2[m] : 0.0f) : g.C[(long long)m * g.sCm + n];
+                }
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int m = mb + (q & 3) + 8 * (q >> 2);
+                    if (nok && ((okrow >> q) & 1u)) {
+                        if (last) { if (g.C2 != nullptr) g.C2[m] = old[q] + acc[i][j][q]; }
+                        else g.C[(long long)m * g.sCm + n] = old[q] + acc[i][j][q];
+                    }
+                }
+            } else {
+                const float bn = (nok && g.bias != nullptr) ? g.bias[n] : 0.0f;
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int m = mb + (q & 3) + 8 * (q >> 2);
+                    if (nok && ((okrow >> q) & 1u)) g.C[(long long)m * g.sCm + n] = acc[i][j][q] + bn;
+                }
+            }
+        }
+    }
+}
+
+// C[M][N] (=, +=) A[M][Kd] * B[Kd][N]; one kernel per product of the dense path (each carries only its own LDS tiles).
+// Grids: logits (ceil(M / 128), ceil(N / 128)); dfeat (ceil(M / 128), ceil(N / 192), ksplit); dw (ceil(M / 64), ceil(N / 192)).
+// *n_over == 0 (no dense row in this minibatch: the production case) ends every block at once.
+extern "C" __global__ void __launch_bounds__(256) ksh_head_gemm_logits_kernel(KshGemmArgs g) {     // mode 0
+    if (*g.n_over == 0u) return;
+    ksh_head_gemm_body<0, KSH_GEMM_M0, KSH_GEMM_N0, 1, 1>(g);
+}
+extern "C" __global__ void __launch_bounds__(256) ksh_head_gemm_dfeat_kernel(KshGemmArgs g) {      // mode 1
+    if (*g.n_over == 0u) return;
+    ksh_head_gemm_body<1, KSH_GEMM_M1, KSH_GEMM_N1, 1, 0>(g);
+}
+extern "C" __global__ void __launch_bounds__(256) ksh_head_gemm_dw_kernel(KshGemmArgs g) {         // mode 2
+    if (*g.n_over == 0u) return;
+    ksh_head_gemm_body<2, KSH_GEMM_M2, KSH_GEMM_N2, 0, 0>(g);
 }
 
 // C[m][n] = sum over the ksplit slices (ascending) of Cpart[z][m][n], for the flagged rows only.

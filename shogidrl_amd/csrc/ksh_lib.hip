@@ -531,7 +531,7 @@ static int head_loss_impl(const float *feat, const float *W, const float *bias, 
         g.Bm = W; g.sBk = 1; g.sBn = K;
         g.C = w.zbuf; g.sCm = KSH_PA;
         g.M = B; g.N = KSH_PA; g.Kd = K; g.bias = bias;
-        hipLaunchKernelGGL(ksh_head_gemm_kernel, dim3((B + 63) / 64, (KSH_PA + 63) / 64), gb, 0, st, g);
+        hipLaunchKernelGGL(ksh_head_gemm_logits_kernel, dim3((B + KSH_GEMM_M0 - 1) / KSH_GEMM_M0, (KSH_PA + KSH_GEMM_N0 - 1) / KSH_GEMM_N0), gb, 0, st, g);
         hipLaunchKernelGGL(ksh_ppo_loss_kernel<float>, dim3(B), dim3(KSH_ROW_THREADS), 0, st, L, (const float *)w.zbuf,
                            want_grad ? w.dlbuf : (float *)nullptr);
     }
@@ -566,15 +566,16 @@ static int head_loss_impl(const float *feat, const float *W, const float *bias, 
             g.ksplit = KSH_HEAD_KSPLIT;
             g.kchunk = ((KSH_PA + KSH_HEAD_KSPLIT - 1) / KSH_HEAD_KSPLIT + KSH_GEMM_BK - 1) / KSH_GEMM_BK * KSH_GEMM_BK;
             g.Cpart = w.cpart;
-            hipLaunchKernelGGL(ksh_head_gemm_kernel, dim3((B + 63) / 64, (K + 63) / 64, KSH_HEAD_KSPLIT), gb, 0, st, g);
+            hipLaunchKernelGGL(ksh_head_gemm_dfeat_kernel, dim3((B + KSH_GEMM_M1 - 1) / KSH_GEMM_M1, (K + KSH_GEMM_N1 - 1) / KSH_GEMM_N1, KSH_HEAD_KSPLIT), gb, 0, st, g);
             hipLaunchKernelGGL(ksh_head_splitk_reduce_kernel, dim3(B), gb, 0, st, g);
-            g.ksplit = 0; g.kchunk = 0; g.Cpart = nullptr;
             g.mode = 2;
             g.A = w.dlbuf; g.sAm = 1; g.sAk = KSH_PA;
             g.Bm = feat; g.sBk = K; g.sBn = 1;
             g.C = dW; g.sCm = K; g.C2 = dbias;
             g.M = KSH_PA; g.N = K + 1; g.Kd = B;
-            hipLaunchKernelGGL(ksh_head_gemm_kernel, dim3((KSH_PA + 63) / 64, (K + 1 + 63) / 64), gb, 0, st, g);
+            // (two slices of the sample range + an ordered add were measured: 82 + 10 us against 97 us unsplit -- not kept)
+            g.ksplit = 0; g.kchunk = 0; g.Cpart = nullptr;
+            hipLaunchKernelGGL(ksh_head_gemm_dw_kernel, dim3((KSH_PA + KSH_GEMM_M2 - 1) / KSH_GEMM_M2, (K + 1 + KSH_GEMM_N2 - 1) / KSH_GEMM_N2), gb, 0, st, g);
         }
     }
     HIP_TRY(hipGetLastError());
