@@ -920,7 +920,8 @@ struct KshGemmArgs {
     float *Cpart;
 };
 
-#define KSH_GEMM_BK 16
+#define KSH_GEMM_BK 16        // granularity of a split-K slice (host side); the logits product's K-step
+#define KSH_GEMM_BK_LONG 16   // K-step of the two products with long reductions (32 measured: dfeat 67 -> 73 us, dW 78 -> 102 us: twice the quads in flight spill)
 // block tiles of the three products (rows x columns): see ksh_head_gemm_kernel
 #define KSH_GEMM_M0 64    // mode 0 (logits):  B x 13527
 #define KSH_GEMM_N0 128
@@ -962,9 +963,9 @@ __device__ __forceinline__ float4 ksh_gemm_ld4_fix(ksh_f4a4 v, long long o0, lon
 // contiguous (AKF / BKF: the reduction index k is; else the row / column index is).  LDS holds As[k][m] / Bs[k][n] with a
 // 4-float pad: an MFMA operand read is 32 consecutive words per k (conflict-free), an m- or n-contiguous quad is one 16-byte
 // write, a k-contiguous quad four scalar writes.
-template <int MODE, int BM, int BN, int AKF, int BKF>
+template <int MODE, int BM, int BN, int BK, int AKF, int BKF>
 __device__ __forceinline__ void ksh_head_gemm_body(const KshGemmArgs &g) {
-    constexpr int BK = KSH_GEMM_BK, LDA = BM + 4, LDB = BN + 4;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int CA = BM * BK / 4 / 256, CB = BN * BK / 4 / 256;     // 16-byte chunks per thread and K-step
     static_assert(BM % 64 == 0 && BN % 64 == 0 && CA >= 1 && CB >= 1, "tile shape");
@@ -1290,21 +1291,25 @@ __device__ __forceinline__ void ksh_head_gemm_body(const KshGemmArgs &g) {
                         g.Cpart[((size_t)blockIdx.z * (size_t)g.M + (size_t)m) * (size_t)g.N + (size_t)n] = acc[i][j][q];
                 }
             } else if (MODE == 2) {
+                // += : the old values are loaded four rows at a time (all sixteen at once cost 249 VGPRs: one wave per SIMD)
                 const bool last = n == g.N - 1;          // the constant-1 column: dbias
-                float old[16];
+                float *cbase = last ? g.C2 : g.C + n;
+                const long long cstride = last ? 1 : g.sCm;
+                const bool cok = nok && cbase != nullptr;
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int m = mb + (q & 3) + 8 * (q >> 2);
-                    old[q] = 0.0f;
-                    if (nok && ((okrow >> q) & 1u)) old[q] = last ? (g.C2 != nullptr ? g.C2[m] : 0.0f) : g.C[(long long)m * g.sCm + n];
-                }
+                for (int qg = 0; qg < 4; qg++) {
+                    float old[4];
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int m = mb + (q & 3) + 8 * (q >> 2);
-                    if (nok && ((okrow >> q) & 1u)) {
-                        if (last) { if (g.C2 != nullptr) g.C2[m] = old[q] + acc[i][j][q]; }
-                        else g.C[(long long)m * g.sCm + n] = old[q] + acc[i][j][q];
+                    for (int u = 0; u < 4; u++) {
+                        const int m = mb + u + 8 * qg;
+                        old[u] = (cok && m < g.M) ? cbase[(long long)m * cstride] : 0.0f;
                     }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int m = mb + u + 8 * qg;
+                        if (cok && m < g.M) cbase[(long long)m * cstride] = old[u] + acc[i][j][4 * qg + u];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
                 const float bn = (nok && g.bias != nullptr) ? g.bias[n] : 0.0f;
@@ -1314,6 +1319,7 @@ __device__ __forceinline__ void ksh_head_gemm_body(const KshGemmArgs &g) {
                     if (nok && ((okrow >> q) & 1u)) g.C[(long long)m * g.sCm + n] = acc[i][j][q] + bn;
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);             // one tile's batch of loads at a time (all tiles at once: 249 VGPRs)
         }
     }
 }
@@ -1323,15 +1329,28 @@ __device__ __forceinline__ void ksh_head_gemm_body(const KshGemmArgs &g) {
 // *n_over == 0 (no dense row in this minibatch: the production case) ends every block at once.
 extern "C" __global__ void __launch_bounds__(256) ksh_head_gemm_logits_kernel(KshGemmArgs g) {     // mode 0
     if (*g.n_over == 0u) return;
-    ksh_head_gemm_body<0, KSH_GEMM_M0, KSH_GEMM_N0, 1, 1>(g);
+    ksh_head_gemm_body<0, KSH_GEMM_M0, KSH_GEMM_N0, 16, 1, 1>(g);     // K = 162: 11 steps of 16 (6 of 32 would pad 18 %)
 }
 extern "C" __global__ void __launch_bounds__(256) ksh_head_gemm_dfeat_kernel(KshGemmArgs g) {      // mode 1
     if (*g.n_over == 0u) return;
-    ksh_head_gemm_body<1, KSH_GEMM_M1, KSH_GEMM_N1, 1, 0>(g);
+    ksh_head_gemm_body<1, KSH_GEMM_M1, KSH_GEMM_N1, KSH_GEMM_BK_LONG, 1, 0>(g);
 }
 extern "C" __global__ void __launch_bounds__(256) ksh_head_gemm_dw_kernel(KshGemmArgs g) {         // mode 2
     if (*g.n_over == 0u) return;
-    ksh_head_gemm_body<2, KSH_GEMM_M2, KSH_GEMM_N2, 0, 0>(g);
+    ksh_head_gemm_body<2, KSH_GEMM_M2, KSH_GEMM_N2, KSH_GEMM_BK_LONG, 0, 0>(g);
+}
+
+// dW[m][n] += sum over the ksplit slices (ascending) of Cpart[z][m][n]; column N-1 goes to dbias.  Four rows per block.
+extern "C" __global__ void __launch_bounds__(256) ksh_head_splitk_reduce_dw_kernel(KshGemmArgs g) {
+    if (*g.n_over == 0u) return;
+    const int m = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (m >= g.M) return;
+    for (int n = (int)(threadIdx.x & 63); n < g.N; n += 64) {
+        float v = 0.0f;
+        for (int z = 0; z < g.ksplit; z++) v += g.Cpart[((size_t)z * (size_t)g.M + (size_t)m) * (size_t)g.N + (size_t)n];
+        if (n == g.N - 1) { if (g.C2 != nullptr) g.C2[m] += v; }
+        else g.C[(long long)m * g.sCm + n] += v;
+    }
 }
 
 // C[m][n] = sum over the ksplit slices (ascending) of Cpart[z][m][n], for the flagged rows only.

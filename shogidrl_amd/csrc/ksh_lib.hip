@@ -411,6 +411,7 @@ struct HeadWs {
     size_t bytes;
 };
 #define KSH_HEAD_KSPLIT 32
+#define KSH_HEAD_DW_KSPLIT 2       // dW = dl^T feat: 212 row tiles for 256 CUs, one wave per SIMD -> two slices of the sample range
 static size_t head_align(size_t x) { return (x + 255) & ~(size_t)255; }
 static HeadWs head_ws(void *workspace, int B, int K, int dense, int grad) {      // grad = 0: the evaluate-only layout (no backward scratch)
     HeadWs w;
@@ -442,8 +443,9 @@ static HeadWs head_ws(void *workspace, int B, int K, int dense, int grad) {     
         if (grad) {
             w.dlbuf = (float *)p;
             p += head_align((size_t)KSH_PA * B * 4);
-            w.cpart = (float *)p;                          // split-K partial tiles of the dense dfeat product
-            p += head_align((size_t)KSH_HEAD_KSPLIT * B * K * 4);
+            w.cpart = (float *)p;                          // split-K partial tiles of the dense dfeat / dW products (used in turn)
+            const size_t c1 = (size_t)KSH_HEAD_KSPLIT * B * K * 4, c2 = (size_t)KSH_HEAD_DW_KSPLIT * KSH_PA * (K + 1) * 4;
+            p += head_align(c1 > c2 ? c1 : c2);
         }
     }
     w.bytes = (size_t)(p - (char *)workspace);
@@ -573,9 +575,11 @@ static int head_loss_impl(const float *feat, const float *W, const float *bias, 
             g.Bm = feat; g.sBk = K; g.sBn = 1;
             g.C = dW; g.sCm = K; g.C2 = dbias;
             g.M = KSH_PA; g.N = K + 1; g.Kd = B;
-            // (two slices of the sample range + an ordered add were measured: 82 + 10 us against 97 us unsplit -- not kept)
-            g.ksplit = 0; g.kchunk = 0; g.Cpart = nullptr;
-            hipLaunchKernelGGL(ksh_head_gemm_dw_kernel, dim3((KSH_PA + KSH_GEMM_M2 - 1) / KSH_GEMM_M2, (K + 1 + KSH_GEMM_N2 - 1) / KSH_GEMM_N2), gb, 0, st, g);
+            // 212 row tiles would leave one wave per SIMD and 44 CUs idle: two slices of the sample range, added in order
+            g.ksplit = KSH_HEAD_DW_KSPLIT;
+            g.kchunk = ((B + KSH_HEAD_DW_KSPLIT - 1) / KSH_HEAD_DW_KSPLIT + KSH_GEMM_BK - 1) / KSH_GEMM_BK * KSH_GEMM_BK;
+            hipLaunchKernelGGL(ksh_head_gemm_dw_kernel, dim3((KSH_PA + KSH_GEMM_M2 - 1) / KSH_GEMM_M2, (K + 1 + KSH_GEMM_N2 - 1) / KSH_GEMM_N2, KSH_HEAD_DW_KSPLIT), gb, 0, st, g);
+            hipLaunchKernelGGL(ksh_head_splitk_reduce_dw_kernel, dim3((KSH_PA + 3) / 4), gb, 0, st, g);
         }
     }
     HIP_TRY(hipGetLastError());
