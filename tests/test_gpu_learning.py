@@ -4,7 +4,9 @@ can see.  tools/learn_sanity.py trains 60 self-play iterations (1024 games x 64 
 hyper-parameters: default_config.yaml:79-116 lr 3e-4, clip 0.2, entropy 0.01, stored old log-probs) from random init and
 plays `evaluate_match(policy, UniformRandomPolicy)` (single_opponent.py:170-220 batched, colours balanced, 512 games) before
 and after.  Measured on the MI355X (profiles/r03_learn_sanity_reference_hyperparameters_*.log): arg-max win rate 0.14 -> 0.39, max-move draws
-224 -> 118 of 512, finished self-play games per iteration 136 -> 235; 46 s.  The margins below are half of that."""
+224 -> 118 of 512, finished self-play games per iteration 136 -> 235; 46 s.  Runs differ (MIOpen's atomics-based weight
+gradients, sampling): the weakest of four runs had arg-max 0.15 -> 0.30, sampled 0.28 -> 0.39, draws 194 -> 157 / 234 -> 131.
+The margins below are about half of THAT run's."""
 import json
 import os
 import subprocess
@@ -23,10 +25,11 @@ def test_self_play_training_beats_its_untrained_self_against_a_random_opponent()
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     u, t = d["untrained"], d["trained"]
     print("untrained %s\ntrained   %s" % (json.dumps(u), json.dumps(t)))
-    assert t["argmax"]["win_rate"] >= u["argmax"]["win_rate"] + 0.12, (u["argmax"], t["argmax"])
-    assert t["sampled"]["win_rate"] >= u["sampled"]["win_rate"] + 0.06, (u["sampled"], t["sampled"])
-    assert t["argmax"]["draws"] <= u["argmax"]["draws"] - 50            # games get DECIDED: that is what +1-for-the-mate teaches
-    assert d["episodes_per_iter_last_fifth"] >= 1.3 * d["episodes_per_iter_first_fifth"]
+    assert t["argmax"]["win_rate"] >= u["argmax"]["win_rate"] + 0.08, (u["argmax"], t["argmax"])
+    assert t["sampled"]["win_rate"] >= u["sampled"]["win_rate"] + 0.05, (u["sampled"], t["sampled"])
+    # games get DECIDED: that is what +1-for-the-mate teaches (both evaluation modes together, 1024 games)
+    assert t["argmax"]["draws"] + t["sampled"]["draws"] <= u["argmax"]["draws"] + u["sampled"]["draws"] - 60
+    assert d["episodes_per_iter_last_fifth"] >= 1.2 * d["episodes_per_iter_first_fifth"]
     for side in (u, t):
         for mode in ("sampled", "argmax"):
             m = side[mode]
