@@ -965,7 +965,10 @@ __device__ __forceinline__ float4 ksh_gemm_ld4_fix(ksh_f4a4 v, long long o0, lon
 // write, a k-contiguous quad four scalar writes.
 template <int MODE, int BM, int BN, int BK, int AKF, int BKF>
 __device__ __forceinline__ void ksh_head_gemm_body(const KshGemmArgs &g) {
-    constexpr int LDA = BM + 4, LDB = BN + 4;
+    // row pads: a k-contiguous operand is written to LDS as scalars, lane = (row i = c / 4, k-quad c % 4): a row stride of
+    // 2 (mod 32) puts the 32 lanes of a half-wave (8 rows x 4 quads) on 32 different banks (4 (mod 32): 2-way conflicts,
+    // 1.8 M conflict cycles per logits launch); an m- / n-contiguous operand is written as 16-byte quads and keeps the pad of 4
+    constexpr int LDA = BM + (AKF ? 2 : 4), LDB = BN + (BKF ? 2 : 4);
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int CA = BM * BK / 4 / 256, CB = BN * BK / 4 / 256;     // 16-byte chunks per thread and K-step
     static_assert(BM % 64 == 0 && BN % 64 == 0 && CA >= 1 && CB >= 1, "tile shape");
