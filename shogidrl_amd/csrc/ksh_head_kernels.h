@@ -889,10 +889,10 @@ extern "C" __global__ void __launch_bounds__(KSH_ROW_THREADS) ksh_pack_mask_kern
 }
 
 // ------------------------------------------------------------------------------------------ dense rows: MFMA GEMM
-// C[M][N] (=, +=) A[M][Kd] * B[Kd][N] on v_mfma_f32_32x32x2_f32 (float32 in, float32 accumulate: bit for bit a k-ordered
-// fmaf chain).  64x64 block tile, four waves of one 32x32 tile each, K-step 16 staged through LDS as As[k][m] / Bs[k][n]
-// (a lane reads A[m = lane & 31][k = lane >> 5] and B[k][n = lane & 31]: consecutive lanes, consecutive LDS words).
-// Operands are addressed through (row, column) strides so that the three products of the dense path share the code:
+// C[M][N] (=, +=) A[M][Kd] * B[Kd][N] on v_mfma_f32_32x32x2_f32 (float32 in, float32 accumulate, k ascending).  One body
+// (ksh_head_gemm_body, below) instantiated per product with its own block tile; K-step 16 staged through LDS as As[k][m] /
+// Bs[k][n] (a lane reads A[m = lane & 31][k = lane >> 5] and B[k][n = lane & 31]: consecutive lanes, consecutive LDS words).
+// Operands are addressed through (row, column) strides; the three products of the dense path:
 //   mode 0  logits[r][a]  = sum_k feat[r][k] W[a][k] + bias[a]      rows gated: only tiles / rows flagged as dense
 //   mode 1  dfeat[r][k]   = sum_a dl[r][a] W[a][k]                  rows gated likewise
 //   mode 2  dW[a][k]     += sum_r dl[r][a] feat[r][k], dbias[a] += sum_r dl[r][a]   (reduction over the flagged rows only;
@@ -922,7 +922,7 @@ struct KshGemmArgs {
 
 #define KSH_GEMM_BK 16        // granularity of a split-K slice (host side); the logits product's K-step
 #define KSH_GEMM_BK_LONG 16   // K-step of the two products with long reductions (32 measured: dfeat 67 -> 73 us, dW 78 -> 102 us: twice the quads in flight spill)
-// block tiles of the three products (rows x columns): see ksh_head_gemm_kernel
+// block tiles of the three products (rows x columns): see ksh_head_gemm_body
 #define KSH_GEMM_M0 64    // mode 0 (logits):  B x 13527
 #define KSH_GEMM_N0 128
 #define KSH_GEMM_M1 128   // mode 1 (dfeat):   B x K, reduction over the 13 527 actions split KSH_HEAD_KSPLIT ways
