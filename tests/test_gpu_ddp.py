@@ -228,3 +228,43 @@ def test_bench_one_rank_rccl_rehearsal():
     out = json.loads(r.stdout)
     assert out["backend"] == "nccl (RCCL)" and out["world_size"] == 1 and out["n_gpus"] == 1 and out["value"] > 0
     assert all(v == v for v in out["ppo_metrics"].values())      # finite metrics after all-reduced updates
+
+
+def test_bench_under_torch_distributed_run_with_four_ranks_sharing_the_gpu(tmp_path):
+    """The driver's command line for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` -- with the REAL job (env kernel, tower, PPO update) at toy size: four
+    ranks, rank 0 as supervisor + worker, gloo collectives, every rank with its own MIOpen user-db / kernel-cache directory
+    (MIOpen really creates its databases there).  On a box with fewer than four GPUs the ranks share one (explicit switch);
+    with four or more they take one each and the collectives run over RCCL."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "KSH_ALLOW_GPU_SHARING", "KSH_DIST_BACKEND", "MIOPEN_USER_DB_PATH",
+              "MIOPEN_CUSTOM_CACHE_DIR"):
+        env.pop(k, None)
+    four = torch.cuda.device_count() >= 4
+    if not four:
+        env.update(KSH_ALLOW_GPU_SHARING="1", KSH_DIST_BACKEND="gloo")
+    env["KSH_MIOPEN_DB_BASE"] = str(tmp_path)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1", "--games", "64",
+           "--rollout", "4", "--epochs", "1", "--minibatch", "128", "--depth", "1", "--width", "32", "--replay", "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["world_size"] == 4 and out["backend"].startswith("nccl" if four else "gloo")
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0 and "cpu_baseline" not in out and "worker_exit" not in out
+    assert all(v == v for v in out["ppo_metrics"].values())
+    made = sorted(d for d in os.listdir(tmp_path) if d.startswith("rank"))
+    assert made == ["rank0", "rank1", "rank2", "rank3"]
+    assert all(os.listdir(os.path.join(tmp_path, d, "db")) or os.listdir(os.path.join(tmp_path, d, "cache")) for d in made), \
+        "MIOpen did not use the per-rank directories"
