@@ -1051,6 +1051,10 @@ __device__ __forceinline__ void ksh_head_gemm_body(const KshGemmArgs &g) {
         else {
             const long long left = re - o0;                // valid rows m in this quad
             keepa[q] = left >= 4 ? 15u : (left <= 0 ? 0u : ((1u << (int)left) - 1u));
+            // a quad that lies entirely beyond the operand's columns (tile wider than the matrix) is masked to zero anyway:
+            // it is loaded from the START of its k-row instead, or the interior steps near the operand's last rows would
+            // read past the end of the tensor (found by the emulator's AddressSanitizer build, K = 10: up to 764 bytes)
+            if (left <= 0) pa[q] = g.A + (o0 - (m0 + (t + 256 * q - ((t + 256 * q) / (BM / 4)) * (BM / 4)) * 4));
         }
     }
 #pragma unroll
@@ -1062,6 +1066,7 @@ __device__ __forceinline__ void ksh_head_gemm_body(const KshGemmArgs &g) {
         else {
             const long long left = re - o0;
             keepb[q] = left >= 4 ? 15u : (left <= 0 ? 0u : ((1u << (int)left) - 1u));
+            if (left <= 0) pb[q] = g.Bm + (o0 - (n0 + (t + 256 * q - ((t + 256 * q) / (BN / 4)) * (BN / 4)) * 4));   // (as above)
         }
     }
     const long long ska = AKF ? 1 : g.sAk, skb = BKF ? 1 : g.sBk;   // float stride of one k

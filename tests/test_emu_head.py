@@ -25,7 +25,9 @@ def test_emu_head_loss_golden_reference_autograd():
 
 
 # (K = 1296, the tiny CNN's head, and larger batches run on the GPU only: every emulated call walks all 13 527 actions)
-@pytest.mark.parametrize("B,K,vc,dense,empty", [(5, 162, 0, 0, 0), (6, 162, 1, 1, 1)])
+# (the K = 10 and K = 190 cases put dense rows through the tile kernel's edge logic: a reduction shorter than one K-step, a k tail
+# that is not a multiple of four, quads that would leave the last row of `feat` / `W` / the scratch)
+@pytest.mark.parametrize("B,K,vc,dense,empty", [(5, 162, 0, 0, 0), (6, 162, 1, 1, 1), (3, 10, 0, 2, 0), (4, 190, 1, 3, 1)])
 def test_emu_head_loss_vs_oracle(B, K, vc, dense, empty):
     headcheck.check_head_loss_vs_oracle(ops, B, K, seed=B + K, value_clip=vc, dense_rows=dense, empty_rows=empty)
 
