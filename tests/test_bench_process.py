@@ -163,3 +163,18 @@ def test_graph_guard_refuses_and_enables(monkeypatch):
     # setting the variable by hand AFTER the runtime may have read its flags does not count
     monkeypatch.setattr(graphs, "_set_in_time", False)
     assert not graphs.packet_capture_off()
+
+
+def test_cpu_baseline_uses_every_core_of_the_affinity_mask_and_is_bounded_by_wall_time():
+    """`cpu_baseline.all_cores.cores` = len(os.sched_getaffinity(0)), not a cap; the sample is bounded by
+    wall time whatever the cgroup grants (a fixed step count took 190 s on a 256-thread / 16-CPU box)."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    t0 = time.time()
+    cb = bench.cpu_baseline(0.5)
+    assert time.time() - t0 < 20
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "NOT with `value`" in cb["sample"]
+    ac = cb["all_cores"]
+    assert ac["cores"] == len(os.sched_getaffinity(0)) == ac["usable_cores"] and ac["host_cpu_count"] == os.cpu_count()
+    assert ac["value"] > 0 and "cgroup_cpu_limit" in ac
