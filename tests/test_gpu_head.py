@@ -95,6 +95,46 @@ def test_gpu_mfma_dense_path_all_rows_dense_equals_torch():
         np.testing.assert_allclose(g.cpu().numpy(), t.grad.cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=name)
 
 
+def test_gpu_mfma_dense_rows_far_apart_in_a_batch_longer_than_one_step_window():
+    """16 500 rows, three of them dense (all-ones masks) at indices 5, 16 450 and 16 499: the weight-gradient product reduces
+    over the SAMPLES in two slices of 8 256 / 8 244 rows, walks each slice's K-steps in windows of 512 (= 8 192 samples) and
+    takes only the steps that hold a flagged row -- here one step in the first window of slice 0 and two in the SECOND window
+    of slice 1, the last of them the range's tail step (16 500 = 1031 * 16 + 4).  Compared with plain PyTorch float32 autograd
+    of the same arithmetic (masked soft-max for the sparse rows)."""
+    from shogidrl_amd import ops as O
+    torch.manual_seed(3)
+    B, K, dev = 16500, 16, "cuda:0"
+    feat = torch.randn(B, K, device=dev, requires_grad=True)
+    W = (torch.randn(A, K, device=dev) * 0.3).requires_grad_(True)
+    b = (torch.randn(A, device=dev) * 0.3).requires_grad_(True)
+    values = torch.randn(B, device=dev, requires_grad=True)
+    mask = torch.zeros(B, A, dtype=torch.bool, device=dev)
+    idx = torch.randint(0, A, (B, 40), device=dev)
+    mask.scatter_(1, idx, True)                                         # ~40 legal actions per sparse row
+    for r in (5, 16450, 16499):
+        mask[r] = True
+    actions = idx[:, 0].clone()
+    old_lp = torch.full((B,), -3.5, device=dev) + 0.1 * torch.randn(B, device=dev)
+    adv, ret = torch.randn(B, device=dev), torch.randn(B, device=dev)
+    loss, stats = O.policy_head_ppo_loss(feat, W, b, values, mask, actions, old_lp, adv, ret, None, 0.2, 0.5, 0.01, False)
+    loss.backward()
+    got = [feat.grad.clone(), W.grad.clone(), b.grad.clone(), values.grad.clone()]
+    for t in (feat, W, b, values):
+        t.grad = None
+    logits = torch.where(mask, feat @ W.t() + b, torch.full((), float("-inf"), device=dev))
+    p = torch.softmax(logits, dim=1)
+    dist = torch.distributions.Categorical(probs=p)
+    new_lp, H = dist.log_prob(actions), dist.entropy()
+    ratio = torch.exp(new_lp - old_lp)
+    pl = -torch.min(ratio * adv, torch.clamp(ratio, 0.8, 1.2) * adv).mean()
+    vl = torch.nn.functional.mse_loss(values, ret)
+    ref = pl + 0.5 * vl + 0.01 * (-H.mean())
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 5e-5 * max(1.0, abs(float(ref)))
+    for g, t, name in zip(got, (feat, W, b, values), ("dfeat", "dW", "dbias", "dvalues")):
+        np.testing.assert_allclose(g.cpu().numpy(), t.grad.cpu().numpy(), rtol=5e-4, atol=5e-7, err_msg=name)
+
+
 @pytest.mark.parametrize("N", [4096, 8192])
 def test_gpu_fused_head_agrees_with_logits_kernels_on_self_play_masks(N):
     """production shape: 4096 (and 8192: two 256-sample windows per segment) rows of real self-play masks, K = 162.  The fused sampler draws the same actions as the
