@@ -548,6 +548,10 @@ def worker_main(args):
         torch.cuda.set_device(local_rank)
         emit(env_roofline("cuda:%d" % local_rank, args.games, args.replay, 42))
         return 0
+    stand_in = JOB_FACTORY is not SelfPlayJob
+    if stand_in and os.environ.get("KSH_BENCH_REHEARSAL_STAND_IN") != "1":
+        # there is no CPU path: anything but the GPU job is the test suite's dress rehearsal, and has to say so
+        raise SystemExit("bench.py: JOB_FACTORY was replaced without KSH_BENCH_REHEARSAL_STAND_IN=1 (tests/helpers/bench_rehearsal.py)")
     job = JOB_FACTORY(args, rank, local_rank, world)
     barrier = _barrier_fn(job, local_rank)
     job.prepare(note)
@@ -625,6 +629,8 @@ def worker_main(args):
             head["selfplay_env_steps_per_s"] = transitions / (roll_ms * 1e-3)
             head["ppo_samples_per_s"] = transitions * args.epochs / (upd_ms * 1e-3)
         head.update(job.extra_headline())
+        if stand_in:
+            head["rehearsal_stand_in"] = True     # NOT a measurement: the rank's GPU job was replaced by the tests' CPU stand-in
         stages.put("headline", head)              # from here on the measurement cannot be lost (supervisor) ...
         note("headline: %.1f env-steps/s (%.1f ms per step)" % (head["value"], head["ms_per_step"]))
         for name, fn in job.side_figures():

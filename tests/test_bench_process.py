@@ -50,6 +50,7 @@ def test_single_rank_line_comes_from_the_supervisor_and_has_every_part():
         assert k in out, k
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and "worker_exit" not in out
     assert out["config"]["old_log_probs"].startswith("as stored")      # the reference's semantics are the default
+    assert out["rehearsal_stand_in"] is True                          # a line from the stand-in can never pass for a measurement
 
 
 def test_a_worker_that_dies_in_a_side_figure_cannot_remove_the_headline():
