@@ -923,12 +923,24 @@ struct KshGemmArgs {
 #define KSH_GEMM_BK 16        // granularity of a split-K slice (host side); the logits product's K-step
 #define KSH_GEMM_BK_LONG 16   // K-step of the two products with long reductions (32 measured: dfeat 67 -> 73 us, dW 78 -> 102 us: twice the quads in flight spill)
 // block tiles of the three products (rows x columns): see ksh_head_gemm_body
+#ifndef KSH_GEMM_M0
 #define KSH_GEMM_M0 64    // mode 0 (logits):  B x 13527
-#define KSH_GEMM_N0 128
+#endif
+#ifndef KSH_GEMM_N0
+#define KSH_GEMM_N0 64    // (tile grid measured: 64x64 69.5 us, 128x64 72.9, 64x128 73-76, 128x128 84, 64x256 87)
+#endif
+#ifndef KSH_GEMM_M1
 #define KSH_GEMM_M1 128   // mode 1 (dfeat):   B x K, reduction over the 13 527 actions split KSH_HEAD_KSPLIT ways
+#endif
+#ifndef KSH_GEMM_N1
 #define KSH_GEMM_N1 192
+#endif
+#ifndef KSH_GEMM_M2
 #define KSH_GEMM_M2 64    // mode 2 (dW):      13527 x (K + 1), reduction over the samples
+#endif
+#ifndef KSH_GEMM_N2
 #define KSH_GEMM_N2 192
+#endif
 
 struct __attribute__((packed, aligned(4))) ksh_f4a4 {   // four floats at a dword-aligned address (gfx9: global_load_dwordx4 needs no more)
     float x, y, z, w;

@@ -410,8 +410,12 @@ struct HeadWs {
     int BW, SEGW, NSEG;
     size_t bytes;
 };
+#ifndef KSH_HEAD_KSPLIT
 #define KSH_HEAD_KSPLIT 32
+#endif
+#ifndef KSH_HEAD_DW_KSPLIT
 #define KSH_HEAD_DW_KSPLIT 2       // dW = dl^T feat: 212 row tiles for 256 CUs, one wave per SIMD -> two slices of the sample range
+#endif
 static size_t head_align(size_t x) { return (x + 255) & ~(size_t)255; }
 static HeadWs head_ws(void *workspace, int B, int K, int dense, int grad) {      // grad = 0: the evaluate-only layout (no backward scratch)
     HeadWs w;
